@@ -1,0 +1,138 @@
+/* jtokkit_amd.h -- C ABI of the MI355X-native batch BPE encoder.
+ *
+ * This is the drop-in boundary for ONE path of JTokkit (reference at /root/reference, paths below
+ * relative to lib/src/main/java/com/knuddels/jtokkit/): GptBytePairEncoding.encode() and its
+ * callers in the Encoding interface.  The reference has no FFI of its own; these are the entry
+ * points a JNI shim behind `com.knuddels.jtokkit.api.Encoding` binds (see INTEGRATION.md for the
+ * Java/JNI side).  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Threading (api/EncodingRegistry.java:51,61 "The encoding must be thread-safe"): a jtk_encoding
+ * is immutable after creation and may be shared by any number of threads.  A jtk_batch owns one
+ * HIP stream plus its device scratch and must be used by one thread at a time; create one per
+ * caller thread.
+ *
+ * Every function that returns int returns JTK_OK (0) or a negative jtk_status.  The message of the
+ * last failure on the calling thread is available from jtk_last_error().
+ */
+#ifndef JTOKKIT_AMD_H
+#define JTOKKIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes; the comment names the exception the Java shim raises for it. */
+typedef enum jtk_status {
+    JTK_OK = 0,
+    JTK_ERR_INVALID_ARGUMENT = -1,    /* IllegalArgumentException (bad call) */
+    JTK_ERR_UNSUPPORTED_SPECIAL = -2, /* UnsupportedOperationException("Encoding special tokens is not
+                                         supported yet.")  GptBytePairEncoding.java:52-56 */
+    JTK_ERR_UNKNOWN_TOKEN = -3,       /* IllegalArgumentException("Unknown token for decoding: " + id)
+                                         GptBytePairEncoding.java:313 */
+    JTK_ERR_CAPACITY = -4,            /* caller buffer too small (shim grows and retries) */
+    JTK_ERR_BAD_RANK_FILE = -5,       /* IllegalStateException  EncodingFactory.java:142,151,162 */
+    JTK_ERR_BAD_UTF8 = -6,            /* input is not what String.getBytes(UTF_8) produces */
+    JTK_ERR_NO_DEVICE = -7,           /* no MI355X / HIP runtime: there is NO CPU fallback */
+    JTK_ERR_HIP = -8,                 /* a HIP call failed; see jtk_last_error() */
+    JTK_ERR_UNSUPPORTED_TABLE = -9,   /* rank table outside what the device path handles (see
+                                         jtk_encoding_create) */
+    JTK_ERR_PIECE_TOO_LONG = -10,     /* a single pre-token piece exceeds JTK_MAX_PIECE_BYTES */
+    JTK_ERR_OUT_OF_MEMORY = -11
+} jtk_status;
+
+/* The two split patterns of EncodingFactory.java:63 (= :77, :91) and :105. */
+enum { JTK_PATTERN_R50K = 0, JTK_PATTERN_CL100K = 1 };
+
+/* Flags of jtk_batch_encode*. */
+enum {
+    JTK_ENCODE_ORDINARY = 1u /* encodeOrdinary(): skip the special-token check of encode()
+                                (GptBytePairEncoding.java:62-64 vs :47-59) */
+};
+
+typedef struct jtk_encoding jtk_encoding;
+typedef struct jtk_batch jtk_batch;
+
+const char* jtk_version(void);
+const char* jtk_last_error(void);
+/* Number of visible HIP devices, or a negative status. */
+int jtk_device_count(void);
+
+/* ---- encoding objects -------------------------------------------------------------------------
+ * Replaces EncodingFactory.fromPredefinedParameters (:121-137) + the GptBytePairEncoding
+ * constructor (GptBytePairEncoding.java:30-35): parses the `.tiktoken` bytes ("base64 SP rank LF",
+ * EncodingFactory.java:139-164), builds the device rank tables and uploads them to `device`.
+ * `special_literals[i]` / `special_ids[i]` are the special tokens (EncodingFactory.java:24-53).
+ *
+ * Tables accepted: all 256 single bytes present, ids < 131071, and bytePairMerge(T) == [rank(T)]
+ * for every table entry T (true for the three shipped tables), so that the whole-piece shortcut of
+ * GptBytePairEncoding.java:81-83 is a pure optimisation; otherwise JTK_ERR_UNSUPPORTED_TABLE. */
+int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tiktoken, size_t tiktoken_len,
+                        const char* const* special_literals, const int32_t* special_ids, int n_specials,
+                        int device, jtk_encoding** out);
+void jtk_encoding_destroy(jtk_encoding* enc);
+const char* jtk_encoding_name(const jtk_encoding* enc);          /* Encoding.getName() */
+int jtk_encoding_device(const jtk_encoding* enc);
+int64_t jtk_encoding_vocab_size(const jtk_encoding* enc);        /* number of rank-table entries */
+int64_t jtk_encoding_pair_count(const jtk_encoding* enc);        /* (left,right) -> rank entries */
+
+/* ---- batch encode: the hot path ------------------------------------------------------------------
+ * Replaces a loop of Encoding.encode(String) / encodeOrdinary(String) / countTokens(String)
+ * (GptBytePairEncoding.java:38-40, 62-64, 122-129) over n_docs documents.
+ *
+ * Input: the documents' String.getBytes(UTF_8) bytes back to back in `utf8`, document d occupying
+ * [doc_off[d], doc_off[d+1]) (doc_off[0] = 0, doc_off[n_docs] = total bytes).
+ * Output (after jtk_batch_fetch / in device memory): token ids of all documents back to back in
+ * document order, document d occupying [tok_off[d], tok_off[d+1]); status[d] = JTK_OK or
+ * JTK_ERR_UNSUPPORTED_SPECIAL / JTK_ERR_BAD_UTF8 / JTK_ERR_PIECE_TOO_LONG for that document.
+ */
+int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out);
+void jtk_batch_destroy(jtk_batch* b);
+
+/* Host buffers: copies the input to the device, runs the kernels, leaves the result on the device.
+ * *n_tokens receives the total token count (this call synchronises). */
+int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs,
+                     uint32_t flags, int64_t* n_tokens);
+
+/* Device buffers already resident in HBM (what bench.py times).  `stream_or_null` = a hipStream_t
+ * to order against, or NULL for the batch's own stream.  With n_tokens == NULL nothing
+ * synchronises; query later with jtk_batch_result(). */
+int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* d_doc_off, int64_t n_docs,
+                            int64_t n_bytes, uint32_t flags, void* stream_or_null, int64_t* n_tokens);
+
+/* Synchronises and reports the totals of the last encode. */
+int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* worst_status);
+
+/* Copies the last result to host buffers: tokens[tokens_cap] (JTK_ERR_CAPACITY if too small),
+ * tok_off[n_docs + 1], status[n_docs]; any of them may be NULL. */
+int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* tok_off, int32_t* status);
+
+/* Device pointers of the last result (valid until the next encode on this batch). */
+int jtk_batch_device_result(jtk_batch* b, const int32_t** d_tokens, const int64_t** d_tok_off,
+                            const int32_t** d_status);
+
+/* Per-kernel device time of the last encode, measured with HIP events on the stream the kernels
+ * ran on (enable first; costs a few event records per encode).  names[i] points to static strings. */
+int jtk_batch_set_profiling(jtk_batch* b, int enabled);
+int jtk_batch_kernel_times(jtk_batch* b, const char** names, float* ms, int cap, int* n);
+
+/* ---- single-document entry points (what the per-call Encoding methods bind) ---------------------
+ * Encoding.encode(String[, maxTokens]) / encodeOrdinary(..) (GptBytePairEncoding.java:38-69):
+ * max_tokens < 0 means "no limit"; otherwise the result is clipped to max_tokens and backed off to
+ * a code-point boundary exactly as :90-100 does, and *truncated gets EncodingResult.isTruncated().
+ * utf8 == NULL mirrors text == null (empty result, :48-50). */
+int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
+               int32_t* tokens, int64_t tokens_cap, int64_t* n_tokens, int* truncated);
+
+/* Encoding.decodeBytes(List<Integer>) (GptBytePairEncoding.java:137-151, 302-314): concatenates the
+ * byte strings of `ids`; *len receives the byte count (out may be NULL to size). */
+int jtk_decode(const jtk_encoding* enc, const int32_t* ids, int64_t n, uint8_t* out, int64_t cap, int64_t* len);
+
+#define JTK_MAX_PIECE_BYTES 8192
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JTOKKIT_AMD_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of libjtokkit_amd.so (the C ABI in include/jtokkit_amd.h).
+
+The shared library is built in-tree by `make -C jtokkit_amd/csrc` (or __graft_entry__.build()).
+There is no fallback: if the library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjtokkit_amd.so")
+
+JTK_OK = 0
+JTK_ERR_INVALID_ARGUMENT = -1
+JTK_ERR_UNSUPPORTED_SPECIAL = -2
+JTK_ERR_UNKNOWN_TOKEN = -3
+JTK_ERR_CAPACITY = -4
+JTK_ERR_BAD_RANK_FILE = -5
+JTK_ERR_BAD_UTF8 = -6
+JTK_ERR_NO_DEVICE = -7
+JTK_ERR_HIP = -8
+JTK_ERR_UNSUPPORTED_TABLE = -9
+JTK_ERR_PIECE_TOO_LONG = -10
+JTK_ERR_OUT_OF_MEMORY = -11
+
+JTK_PATTERN_R50K = 0
+JTK_PATTERN_CL100K = 1
+JTK_ENCODE_ORDINARY = 1
+
+# every symbol include/jtokkit_amd.h declares: (restype, argtypes)
+_p = C.c_void_p
+_i64 = C.c_int64
+SIGNATURES = {
+    "jtk_version": (C.c_char_p, []),
+    "jtk_last_error": (C.c_char_p, []),
+    "jtk_device_count": (C.c_int, []),
+    "jtk_encoding_create": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p),
+                                      C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(_p)]),
+    "jtk_encoding_destroy": (None, [_p]),
+    "jtk_encoding_name": (C.c_char_p, [_p]),
+    "jtk_encoding_device": (C.c_int, [_p]),
+    "jtk_encoding_vocab_size": (_i64, [_p]),
+    "jtk_encoding_pair_count": (_i64, [_p]),
+    "jtk_batch_create": (C.c_int, [_p, C.POINTER(_p)]),
+    "jtk_batch_destroy": (None, [_p]),
+    "jtk_batch_encode": (C.c_int, [_p, _p, _p, _i64, C.c_uint32, C.POINTER(_i64)]),
+    "jtk_batch_encode_device": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_uint32, _p, C.POINTER(_i64)]),
+    "jtk_batch_result": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32)]),
+    "jtk_batch_fetch": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "jtk_batch_device_result": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
+    "jtk_batch_set_profiling": (C.c_int, [_p, C.c_int]),
+    "jtk_batch_kernel_times": (C.c_int, [_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
+    "jtk_encode": (C.c_int, [_p, _p, _i64, C.c_uint32, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "jtk_decode": (C.c_int, [_p, _p, _i64, _p, _i64, C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "jtokkit_amd: %s is missing -- build it with `make -C jtokkit_amd/csrc` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().jtk_last_error().decode("utf-8", "replace")

@@ -1,0 +1,427 @@
+// jtk_abi.cpp -- the C ABI of include/jtokkit_amd.h: encoding objects, batch scratch, kernel
+// orchestration.  Host C++ only; all compute is in jtk_kernels.hip.  There is no CPU fallback:
+// without a HIP device every encode entry point fails with JTK_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/jtokkit_amd.h"
+#include "jtk_kernels.h"
+#include "jtk_tables.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? JTK_ERR_OUT_OF_MEMORY : JTK_ERR_HIP,           \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return JTK_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(JTK_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        cap = want;
+        return JTK_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int N_STAGES = 7;
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "bpe_merge",
+                                           "bpe_merge_long", "tile_scan", "pack"};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct jtk_encoding {
+    JtkHostTables host;
+    int device = 0;
+    DevBuf uc1, uc2, brank, pairs;
+    JtkDeviceTables dt;
+    std::vector<uint32_t> tok_len;   // byte length per id (0 = absent), for the maxTokens back-off
+};
+
+struct jtk_batch {
+    const jtk_encoding* enc = nullptr;
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    DevBuf in_text, in_off;          // staging for the host-buffer entry point
+    DevBuf zeroed;                   // docmask | tokmask | status | result | long_count
+    DevBuf piecemask, blk_pre, tmp_tok, tile_cnt, tile_fs, tile_off, long_list, tokens, tok_off;
+    JtkResult* host_result = nullptr;   // pinned
+    JtkWork work{};
+    bool have_result = false, synced = false;
+    bool profiling = false;
+    hipEvent_t ev[N_STAGES + 1] = {};
+    bool ev_ok = false, ev_recorded = false;
+};
+
+#include "jtk_unicode_tables.h"
+
+extern "C" {
+
+const char* jtk_version(void) { return "jtokkit_amd 0.1 (gfx950; Unicode " JTK_UNICODE_VERSION " class tables)"; }
+const char* jtk_last_error(void) { return g_err.c_str(); }
+
+int jtk_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(JTK_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tiktoken, size_t tiktoken_len,
+                        const char* const* special_literals, const int32_t* special_ids, int n_specials,
+                        int device, jtk_encoding** out) {
+    if (!out) return fail(JTK_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!tiktoken || n_specials < 0 || (n_specials > 0 && (!special_literals || !special_ids)))
+        return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (n_specials > JTK_MAX_SPECIALS) return fail(JTK_ERR_INVALID_ARGUMENT, "too many special tokens");
+    for (int i = 0; i < n_specials; i++) {
+        const size_t l = strlen(special_literals[i]);
+        if (l < 2 || l > JTK_SPECIAL_MAXLEN || special_literals[i][0] != '<' || special_literals[i][1] != '|')
+            return fail(JTK_ERR_INVALID_ARGUMENT, "special-token literals must start with \"<|\" and be at most 32 bytes");
+    }
+    jtk_encoding* enc = new (std::nothrow) jtk_encoding();
+    if (!enc) return fail(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
+    std::string err;
+    int rc = jtk_build_tables(name, pattern_kind, tiktoken, tiktoken_len, special_literals, special_ids, n_specials,
+                              enc->host, err);
+    if (rc != JTK_OK) { delete enc; return fail(rc, err); }
+    enc->tok_len.assign((size_t)enc->host.max_id + 1, 0);
+    for (size_t i = 0; i < enc->tok_len.size(); i++) enc->tok_len[i] = (uint32_t)enc->host.id_to_bytes[i].size();
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        delete enc;
+        return fail(JTK_ERR_NO_DEVICE, "no HIP device: jtokkit_amd has no CPU path");
+    }
+    if (device < 0 || device >= ndev) { delete enc; return fail(JTK_ERR_INVALID_ARGUMENT, "device index out of range"); }
+    enc->device = device;
+    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); delete enc; };
+#define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(JTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    ENC_TRY(hipSetDevice(device));
+    if (enc->uc1.ensure(sizeof(jtk_uc_stage1_init)) || enc->uc2.ensure(sizeof(jtk_uc_stage2_init)) ||
+        enc->brank.ensure(256 * 4) || enc->pairs.ensure(enc->host.pair_slots.size() * 8)) { cleanup(); return JTK_ERR_OUT_OF_MEMORY; }
+    ENC_TRY(hipMemcpy(enc->uc1.p, jtk_uc_stage1_init, sizeof(jtk_uc_stage1_init), hipMemcpyHostToDevice));
+    ENC_TRY(hipMemcpy(enc->uc2.p, jtk_uc_stage2_init, sizeof(jtk_uc_stage2_init), hipMemcpyHostToDevice));
+    ENC_TRY(hipMemcpy(enc->brank.p, enc->host.byte_rank, 256 * 4, hipMemcpyHostToDevice));
+    ENC_TRY(hipMemcpy(enc->pairs.p, enc->host.pair_slots.data(), enc->host.pair_slots.size() * 8, hipMemcpyHostToDevice));
+#undef ENC_TRY
+    JtkDeviceTables& dt = enc->dt;
+    memset(&dt, 0, sizeof(dt));
+    dt.uc.stage1 = (const uint8_t*)enc->uc1.p;
+    dt.uc.stage2 = (const uint32_t*)enc->uc2.p;
+    dt.byte_rank = (const uint32_t*)enc->brank.p;
+    dt.pairs.slots = (const uint64_t*)enc->pairs.p;
+    dt.pairs.bits = enc->host.pair_bits;
+    dt.kind = pattern_kind;
+    dt.n_specials = n_specials;
+    for (int i = 0; i < n_specials; i++) {
+        const size_t l = strlen(special_literals[i]);
+        dt.special_len[i] = (uint8_t)l;
+        memcpy(dt.special[i], special_literals[i], l);
+    }
+    *out = enc;
+    return JTK_OK;
+}
+
+void jtk_encoding_destroy(jtk_encoding* enc) {
+    if (!enc) return;
+    (void)hipSetDevice(enc->device);
+    enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release();
+    delete enc;
+}
+const char* jtk_encoding_name(const jtk_encoding* enc) { return enc ? enc->host.name.c_str() : ""; }
+int jtk_encoding_device(const jtk_encoding* enc) { return enc ? enc->device : -1; }
+int64_t jtk_encoding_vocab_size(const jtk_encoding* enc) { return enc ? enc->host.n_tokens : 0; }
+int64_t jtk_encoding_pair_count(const jtk_encoding* enc) { return enc ? enc->host.n_pairs : 0; }
+
+int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
+    if (!enc || !out) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(enc->device));
+    jtk_batch* b = new (std::nothrow) jtk_batch();
+    if (!b) return fail(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
+    b->enc = enc;
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result, sizeof(JtkResult), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (b->stream) (void)hipStreamDestroy(b->stream);
+        delete b;
+        return fail(JTK_ERR_HIP, std::string("batch create: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return JTK_OK;
+}
+
+void jtk_batch_destroy(jtk_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->enc->device);
+    (void)hipStreamSynchronize(b->stream);
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->blk_pre, &b->tmp_tok, &b->tile_cnt,
+                      &b->tile_fs, &b->tile_off, &b->long_list, &b->tokens, &b->tok_off};
+    for (DevBuf* d : bufs) d->release();
+    if (b->ev_ok) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
+    if (b->host_result) (void)hipHostFree(b->host_result);
+    (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int jtk_batch_set_profiling(jtk_batch* b, int enabled) {
+    if (!b) return fail(JTK_ERR_INVALID_ARGUMENT, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    if (enabled && !b->ev_ok) {
+        for (auto& ev : b->ev) HIP_TRY(hipEventCreate(&ev));
+        b->ev_ok = true;
+    }
+    b->profiling = enabled != 0;
+    b->ev_recorded = false;
+    return JTK_OK;
+}
+
+int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* d_doc_off, int64_t n_docs,
+                            int64_t n_bytes, uint32_t flags, void* stream_or_null, int64_t* n_tokens) {
+    if (!b || n_docs < 0 || n_bytes < 0 || (n_bytes > 0 && !d_utf8) || !d_doc_off)
+        return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (((uintptr_t)d_utf8 & 15u) != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "device text must be 16-byte aligned");
+    if (n_bytes >= (int64_t)1 << 40) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large");
+    const jtk_encoding* enc = b->enc;
+    HIP_TRY(hipSetDevice(enc->device));
+    hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : b->stream;
+
+    JtkWork& w = b->work;
+    w.text = d_utf8;
+    w.doc_off = d_doc_off;
+    w.n_bytes = n_bytes;
+    w.n_docs = n_docs;
+    w.n_words = (n_bytes + 1 + 63) / 64 + 2;
+    w.n_tiles = (n_bytes + 1 + JTK_MERGE_TILE - 1) / JTK_MERGE_TILE;
+
+    const size_t mask_bytes = (size_t)w.n_words * 8;
+    const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
+    const size_t zero_bytes = 2 * mask_bytes + status_bytes + 32;
+    int rc;
+    if ((rc = b->zeroed.ensure(zero_bytes)) || (rc = b->piecemask.ensure(mask_bytes)) ||
+        (rc = b->blk_pre.ensure((size_t)w.n_words * 2)) ||
+        (rc = b->tmp_tok.ensure(((size_t)n_bytes + 64) * 4)) ||
+        (rc = b->tile_cnt.ensure((size_t)w.n_tiles * 4)) || (rc = b->tile_fs.ensure((size_t)w.n_tiles * 8)) ||
+        (rc = b->tile_off.ensure(((size_t)w.n_tiles + 1) * 8)) ||
+        (rc = b->long_list.ensure((size_t)w.n_tiles * sizeof(JtkLongPiece))) ||
+        (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
+        (rc = b->tok_off.ensure(((size_t)n_docs + 1) * 8)))
+        return rc;
+    uint8_t* z = (uint8_t*)b->zeroed.p;
+    w.docmask = (uint64_t*)z;
+    w.tokmask = (uint64_t*)(z + mask_bytes);
+    w.status = (int32_t*)(z + 2 * mask_bytes);
+    w.result = (JtkResult*)(z + 2 * mask_bytes + status_bytes);
+    w.long_count = (uint32_t*)(z + 2 * mask_bytes + status_bytes + 16);
+    w.piecemask = (uint64_t*)b->piecemask.p;
+    w.blk_pre = (uint16_t*)b->blk_pre.p;
+    w.tmp_tok = (int32_t*)b->tmp_tok.p;
+    w.tile_cnt = (uint32_t*)b->tile_cnt.p;
+    w.tile_fs = (int64_t*)b->tile_fs.p;
+    w.tile_off = (int64_t*)b->tile_off.p;
+    w.long_list = (JtkLongPiece*)b->long_list.p;
+    w.tokens = (int32_t*)b->tokens.p;
+    w.tok_off = (int64_t*)b->tok_off.p;
+
+    const bool prof = b->profiling && b->ev_ok;
+    int evi = 0;
+    auto mark = [&]() { if (prof) (void)hipEventRecord(b->ev[evi++], s); };
+
+    mark();
+    HIP_TRY(hipMemsetAsync(b->zeroed.p, 0, zero_bytes, s));
+    jtk_launch_mark_docs(w, s);
+    mark();
+    if (!(flags & JTK_ENCODE_ORDINARY)) jtk_launch_special_check(w, enc->dt, s);
+    mark();
+    jtk_launch_pretok_split(w, enc->dt, s);
+    mark();
+    jtk_launch_bpe_merge(w, enc->dt, s);
+    mark();
+    jtk_launch_bpe_merge_long(w, enc->dt, s);
+    mark();
+    jtk_launch_tile_scan(w, s);
+    mark();
+    jtk_launch_pack(w, s);
+    mark();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->host_result, w.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
+    b->have_result = true;
+    b->synced = false;
+    b->last_stream = s;
+    b->ev_recorded = prof;
+    if (n_tokens) {
+        HIP_TRY(hipStreamSynchronize(s));
+        b->synced = true;
+        *n_tokens = b->host_result->n_tokens;
+    }
+    return JTK_OK;
+}
+
+int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs,
+                     uint32_t flags, int64_t* n_tokens) {
+    if (!b || n_docs < 0 || !doc_off) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (doc_off[0] != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off[0] must be 0");
+    for (int64_t d = 0; d < n_docs; d++)
+        if (doc_off[d + 1] < doc_off[d]) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off must be non-decreasing");
+    const int64_t n_bytes = doc_off[n_docs];
+    if (n_bytes > 0 && !utf8) return fail(JTK_ERR_INVALID_ARGUMENT, "utf8 is NULL");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    int rc;
+    if ((rc = b->in_text.ensure((size_t)n_bytes + 64)) || (rc = b->in_off.ensure(((size_t)n_docs + 1) * 8))) return rc;
+    if (n_bytes > 0) HIP_TRY(hipMemcpyAsync(b->in_text.p, utf8, (size_t)n_bytes, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->in_off.p, doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    int64_t nt = 0;
+    rc = jtk_batch_encode_device(b, (const uint8_t*)b->in_text.p, (const int64_t*)b->in_off.p, n_docs, n_bytes, flags,
+                                 nullptr, &nt);
+    if (rc != JTK_OK) return rc;
+    if (n_tokens) *n_tokens = nt;
+    return JTK_OK;
+}
+
+int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* worst_status) {
+    if (!b || !b->have_result) return fail(JTK_ERR_INVALID_ARGUMENT, "no encode has run on this batch");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
+    if (n_tokens) *n_tokens = b->host_result->n_tokens;
+    if (n_docs) *n_docs = b->work.n_docs;
+    if (worst_status) *worst_status = b->host_result->worst_status;
+    return JTK_OK;
+}
+
+int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* tok_off, int32_t* status) {
+    int64_t nt = 0;
+    int rc = jtk_batch_result(b, &nt, nullptr, nullptr);
+    if (rc != JTK_OK) return rc;
+    if (tokens) {
+        if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
+        if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->work.tokens, (size_t)nt * 4, hipMemcpyDeviceToHost));
+    }
+    if (tok_off) HIP_TRY(hipMemcpy(tok_off, b->work.tok_off, ((size_t)b->work.n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (status && b->work.n_docs > 0)
+        HIP_TRY(hipMemcpy(status, b->work.status, (size_t)b->work.n_docs * 4, hipMemcpyDeviceToHost));
+    return JTK_OK;
+}
+
+int jtk_batch_device_result(jtk_batch* b, const int32_t** d_tokens, const int64_t** d_tok_off,
+                            const int32_t** d_status) {
+    if (!b || !b->have_result) return fail(JTK_ERR_INVALID_ARGUMENT, "no encode has run on this batch");
+    if (d_tokens) *d_tokens = b->work.tokens;
+    if (d_tok_off) *d_tok_off = b->work.tok_off;
+    if (d_status) *d_status = b->work.status;
+    return JTK_OK;
+}
+
+int jtk_batch_kernel_times(jtk_batch* b, const char** names, float* ms, int cap, int* n) {
+    if (!b || !n) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    *n = 0;
+    if (!b->ev_recorded) return fail(JTK_ERR_INVALID_ARGUMENT, "profiling was not enabled for the last encode");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    HIP_TRY(hipEventSynchronize(b->ev[N_STAGES]));
+    for (int i = 0; i < N_STAGES && i < cap; i++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]));
+        if (names) names[i] = STAGE_NAMES[i];
+        if (ms) ms[i] = t;
+        *n = i + 1;
+    }
+    return JTK_OK;
+}
+
+int jtk_decode(const jtk_encoding* enc, const int32_t* ids, int64_t n, uint8_t* out, int64_t cap, int64_t* len) {
+    if (!enc || n < 0 || (n > 0 && !ids)) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    const int64_t r = jtk_host_decode(enc->host, ids, n, out, cap);
+    if (r == JTK_ERR_UNKNOWN_TOKEN) return fail(JTK_ERR_UNKNOWN_TOKEN, "Unknown token for decoding");
+    if (r < 0) return fail((int)r, "decode buffer too small");
+    if (len) *len = r;
+    return JTK_OK;
+}
+
+// UTF-16 length of well-formed UTF-8 (String.length())
+static int64_t utf16_len(const uint8_t* s, int64_t n) {
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++) if ((s[i] & 0xC0) != 0x80) k += (s[i] >= 0xF0) ? 2 : 1;
+    return k;
+}
+
+int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
+               int32_t* tokens, int64_t tokens_cap, int64_t* n_tokens, int* truncated) {
+    if (!b || len < 0) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (truncated) *truncated = 0;
+    if (n_tokens) *n_tokens = 0;
+    if (!utf8) return JTK_OK;                                    // text == null -> empty result
+    const int64_t off[2] = {0, len};
+    int64_t nt = 0;
+    int rc = jtk_batch_encode(b, utf8, off, 1, flags, &nt);
+    if (rc != JTK_OK) return rc;
+    int32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, b->work.status, 4, hipMemcpyDeviceToHost));
+    if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
+    if (st != JTK_OK) return fail(st, "document could not be encoded");
+    if (max_tokens < 0) {
+        if (n_tokens) *n_tokens = nt;
+        if (tokens) {
+            if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
+            if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->work.tokens, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        }
+        return JTK_OK;
+    }
+    // encode(text, maxTokens): pieces encode independently, so the list before the back-off of
+    // GptBytePairEncoding.java:90-100 is the first min(maxTokens, total) tokens of the full result.
+    int64_t keep = nt < max_tokens ? nt : max_tokens;
+    std::vector<int32_t> head((size_t)(keep > 0 ? keep : 1));
+    if (keep > 0) HIP_TRY(hipMemcpy(head.data(), b->work.tokens, (size_t)keep * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> cum((size_t)keep + 1, 0);
+    for (int64_t k = 0; k < keep; k++) cum[(size_t)k + 1] = cum[(size_t)k] + b->enc->tok_len[(size_t)head[(size_t)k]];
+    const int64_t text16 = utf16_len(utf8, len);
+    for (;; keep--) {
+        // decode(tokens) is the byte prefix [0, nb) of the text.  text.startsWith(decoded) holds when
+        // nb is a code-point boundary, or when the cut character decodes to one U+FFFD and the text
+        // has U+FFFD there.
+        const int64_t nb = cum[(size_t)keep];
+        const bool boundary = (nb == len) || ((utf8[nb] & 0xC0) != 0x80);
+        int64_t dec16;
+        bool starts;
+        if (boundary) { dec16 = utf16_len(utf8, nb); starts = true; }
+        else {
+            int64_t c = nb;
+            while (c > 0 && (utf8[c] & 0xC0) == 0x80) c--;
+            dec16 = utf16_len(utf8, c) + 1;
+            starts = (c + 2 < len) && utf8[c] == 0xEF && utf8[c + 1] == 0xBF && utf8[c + 2] == 0xBD;
+        }
+        if (starts) {
+            if (truncated) *truncated = text16 > dec16;
+            break;
+        }
+        if (keep == 0) break;
+    }
+    if (n_tokens) *n_tokens = keep;
+    if (tokens) {
+        if (tokens_cap < keep) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
+        if (keep > 0) memcpy(tokens, head.data(), (size_t)keep * 4);
+    }
+    return JTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// jtk_common.h -- definitions shared by the host table builder and the gfx950 kernels.
+#ifndef JTK_COMMON_H
+#define JTK_COMMON_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
+#include <hip/hip_runtime.h>
+#define JTK_HD __host__ __device__ __forceinline__
+#else
+#define JTK_HD inline
+#endif
+
+// ---- per-byte class codes produced by the classify stage ------------------------------------------
+// bits 0-1: class of the character this byte belongs to (continuation bytes inherit their lead's)
+enum : uint32_t {
+    JTK_CLS_O = 0,   // [^\s\p{L}\p{N}]
+    JTK_CLS_L = 1,   // \p{L}
+    JTK_CLS_N = 2,   // \p{N}
+    JTK_CLS_W = 3,   // \s  (Unicode White_Space as the JDK defines it under UNICODE_CHARACTER_CLASS)
+    JTK_CB_CLS = 3,
+    JTK_CB_CONT = 4,   // UTF-8 continuation byte (not a character start)
+    JTK_CB_NL = 8,     // '\r' or '\n'
+    JTK_CB_SP = 16,    // U+0020
+    JTK_CB_DS = 32     // a document starts at this byte; also set for every position >= n_bytes
+};
+
+enum { JTK_PAT_R50K = 0, JTK_PAT_CL100K = 1 };
+
+// ---- rank-table encoding ----------------------------------------------------------------------------
+// Every part of a piece during bytePairMerge is itself a table token (all 256 single bytes are
+// tokens and a merge happens only on a table hit, GptBytePairEncoding.java:247-259), and the rank
+// of a token is its id.  So getRank (GptBytePairEncoding.java:285-300) on the byte span of two
+// adjacent parts equals a lookup of (id_left, id_right) in a table holding every split
+// T = A + B with A, B, T all table tokens:  pair(id(A), id(B)) = rank(T).
+// Slot layout: key = id_left << 17 | id_right (34 bits) in the high bits, rank in the low 30.
+#define JTK_ID_BITS 17
+#define JTK_MAX_ID ((1u << JTK_ID_BITS) - 2)
+#define JTK_RANK_NONE 0x7FFFFFFFu          // Integer.MAX_VALUE of the reference
+#define JTK_ID_DEAD 0xFFFFFFFFu            // byte position that does not start a part
+#define JTK_PAIR_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define JTK_PAIR_RANK_MASK 0x3FFFFFFFull
+
+JTK_HD uint64_t jtk_pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << JTK_ID_BITS) | b; }
+
+// 32-bit mix of the two ids; `bits` = log2(table slots).
+JTK_HD uint32_t jtk_pair_hash(uint32_t a, uint32_t b, uint32_t bits) {
+    uint32_t h = a * 0x9E3779B1u + b * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    return h >> (32 - bits);
+}
+
+struct JtkPairTable {
+    const uint64_t* slots;
+    uint32_t bits;   // log2(#slots)
+};
+
+JTK_HD uint32_t jtk_pair_lookup(const JtkPairTable& t, uint32_t a, uint32_t b) {
+    const uint64_t key = jtk_pair_key(a, b);
+    const uint32_t mask = (1u << t.bits) - 1;
+    uint32_t h = jtk_pair_hash(a, b, t.bits);
+    for (;;) {
+        const uint64_t s = t.slots[h];
+        if ((s >> 30) == key) return (uint32_t)(s & JTK_PAIR_RANK_MASK);
+        if (s == JTK_PAIR_EMPTY) return JTK_RANK_NONE;
+        h = (h + 1) & mask;
+    }
+}
+
+// ---- Unicode class lookup ----------------------------------------------------------------------------
+struct JtkUcTables {
+    const uint8_t* stage1;    // [0x1100]  cp >> 8 -> block
+    const uint32_t* stage2;   // [blocks*16] 16 x 2-bit classes per word
+};
+
+JTK_HD uint32_t jtk_class_of_cp(const JtkUcTables& u, uint32_t cp) {
+    if (cp > 0x10FFFFu) return JTK_CLS_O;
+    const uint32_t blk = u.stage1[cp >> 8];
+    const uint32_t w = u.stage2[blk * 16 + ((cp & 255u) >> 4)];
+    return (w >> (2 * (cp & 15u))) & 3u;
+}
+
+JTK_HD uint32_t jtk_class_of_ascii(uint32_t b) {
+    if (((b | 0x20u) - 'a') < 26u) return JTK_CLS_L;
+    if ((b - '0') < 10u) return JTK_CLS_N;
+    if (b == 0x20u || (b - 9u) < 5u) return JTK_CLS_W;
+    return JTK_CLS_O;
+}
+
+// Class byte of position p.  `T` supplies byte(p) (0 outside the buffer).  Input is assumed to be
+// well-formed UTF-8 (String.getBytes(UTF_8)); on malformed input the result is some class, never an
+// out-of-range access.
+template <class T>
+JTK_HD uint32_t jtk_class_byte(const T& txt, const JtkUcTables& u, int64_t p) {
+    const uint32_t b = txt.byte(p);
+    if (b < 0x80u) {
+        uint32_t cb = jtk_class_of_ascii(b);
+        if (b == '\r' || b == '\n') cb |= JTK_CB_NL;
+        if (b == 0x20u) cb |= JTK_CB_SP;
+        return cb;
+    }
+    int64_t lead = p;
+    uint32_t flags = 0;
+    if ((b & 0xC0u) == 0x80u) {
+        flags = JTK_CB_CONT;
+        lead = p - 1;
+        if ((txt.byte(lead) & 0xC0u) == 0x80u) {
+            lead = p - 2;
+            if ((txt.byte(lead) & 0xC0u) == 0x80u) lead = p - 3;
+        }
+    }
+    const uint32_t b0 = txt.byte(lead);
+    uint32_t cp;
+    if (b0 < 0xE0u) cp = ((b0 & 0x1Fu) << 6) | (txt.byte(lead + 1) & 0x3Fu);
+    else if (b0 < 0xF0u) cp = ((b0 & 0x0Fu) << 12) | ((txt.byte(lead + 1) & 0x3Fu) << 6) | (txt.byte(lead + 2) & 0x3Fu);
+    else cp = ((b0 & 0x07u) << 18) | ((txt.byte(lead + 1) & 0x3Fu) << 12) | ((txt.byte(lead + 2) & 0x3Fu) << 6)
+              | (txt.byte(lead + 3) & 0x3Fu);
+    return jtk_class_of_cp(u, cp) | flags;
+}
+
+#endif

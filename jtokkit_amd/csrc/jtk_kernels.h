@@ -1,0 +1,72 @@
+// jtk_kernels.h -- launch interface of the gfx950 kernels (implemented in jtk_kernels.hip).
+#ifndef JTK_KERNELS_H
+#define JTK_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jtk_common.h"
+
+#define JTK_SPLIT_TILE 4096      // bytes per pretok_split workgroup
+#define JTK_SPLIT_HALO 64
+#define JTK_MERGE_TILE 4096      // bytes per bpe_merge workgroup (pieces are owned by the tile they start in)
+#define JTK_MERGE_OVER 256       // a piece may run this far past its tile and still be merged in LDS
+#define JTK_LONG_CAP 8192        // longest piece the long-piece kernel holds in LDS (= JTK_MAX_PIECE_BYTES)
+#define JTK_MAX_SPECIALS 8
+#define JTK_SPECIAL_MAXLEN 32
+
+struct JtkDeviceTables {
+    JtkUcTables uc;
+    const uint32_t* byte_rank;   // [256]
+    JtkPairTable pairs;
+    int kind;
+    int n_specials;
+    uint8_t special_len[JTK_MAX_SPECIALS];
+    uint8_t special[JTK_MAX_SPECIALS][JTK_SPECIAL_MAXLEN];
+};
+
+struct JtkLongPiece {
+    int64_t start;
+    uint32_t len;
+    uint32_t tile;
+};
+
+struct JtkResult {
+    int64_t n_tokens;
+    int32_t worst_status;
+    uint32_t n_long;
+};
+
+// Device-side working set of one encode call (all pointers into the batch's scratch).
+struct JtkWork {
+    const uint8_t* text;
+    const int64_t* doc_off;
+    int64_t n_bytes;
+    int64_t n_docs;
+    int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
+    int64_t n_tiles;        // merge tiles
+    uint64_t* docmask;      // bit p: a document starts at byte p
+    uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)
+    uint64_t* tokmask;      // bit p: a token starts at byte p
+    uint16_t* blk_pre;      // per 64-byte block: tokens its tile owns before the block
+    int32_t* tmp_tok;       // per tile: its tokens, packed from position tile_fs
+    uint32_t* tile_cnt;
+    int64_t* tile_fs;
+    int64_t* tile_off;      // exclusive scan of tile_cnt (n_tiles + 1)
+    JtkLongPiece* long_list;
+    uint32_t* long_count;
+    int32_t* status;        // per document
+    int32_t* tokens;        // output, packed
+    int64_t* tok_off;       // output, n_docs + 1
+    JtkResult* result;
+};
+
+void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
+void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
+void jtk_launch_pack(const JtkWork& w, hipStream_t s);
+
+#endif

@@ -1,0 +1,36 @@
+// jtk_tables.h -- host-side rank tables of one encoding (parsed once, then uploaded).
+#ifndef JTK_TABLES_H
+#define JTK_TABLES_H
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "jtk_common.h"
+
+struct JtkHostTables {
+    std::string name;
+    int kind = 0;
+    // TokenEncoder (TokenEncoder.java:16-17): both directions
+    std::unordered_map<std::string, uint32_t> bytes_to_id;
+    std::vector<std::string> id_to_bytes;        // "" = id absent (p50k has a hole at 50256)
+    std::vector<uint8_t> id_present;
+    std::vector<std::pair<std::string, int32_t>> specials;
+    uint32_t byte_rank[256];                     // id of each single-byte token
+    std::vector<uint64_t> pair_slots;            // open-addressed (left,right) -> rank table
+    uint32_t pair_bits = 0;
+    int64_t n_pairs = 0;
+    int64_t n_tokens = 0;
+    uint32_t max_id = 0;
+};
+
+// Parses `.tiktoken` bytes and builds every derived table.  Returns a jtk_status; `err` gets a message.
+int jtk_build_tables(const char* name, int kind, const uint8_t* tiktoken, size_t len,
+                     const char* const* special_literals, const int32_t* special_ids, int n_specials,
+                     JtkHostTables& out, std::string& err);
+
+// Host decode (Encoding.decodeBytes): returns byte count or a negative status.
+int64_t jtk_host_decode(const JtkHostTables& t, const int32_t* ids, int64_t n, uint8_t* out, int64_t cap);
+
+#endif

@@ -1,0 +1,237 @@
+"""Host-side mirror of the reference's Encoding interface on top of the C ABI.
+
+Mirrors `com.knuddels.jtokkit.api.Encoding` (reference api/Encoding.java:29-189) method for method
+so that parity tests read like the reference's own (reference/Cl100kBaseTestTest.java), plus the
+batch entry points that are the reason this library exists.  The JVM is absent from the build image,
+so this Python class (and the C++ header jtokkit_amd/csrc/jtk_encoding.hpp) stand where the Java
+`HipEncoding implements Encoding` of INTEGRATION.md would.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class UnsupportedOperationError(Exception):
+    """java.lang.UnsupportedOperationException (GptBytePairEncoding.java:54)."""
+
+
+class EncodingError(Exception):
+    def __init__(self, code, msg):
+        super().__init__("jtokkit_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _check(rc):
+    if rc == N.JTK_OK:
+        return
+    msg = N.last_error()
+    if rc == N.JTK_ERR_UNSUPPORTED_SPECIAL:
+        raise UnsupportedOperationError("Encoding special tokens is not supported yet.")
+    if rc == N.JTK_ERR_UNKNOWN_TOKEN:
+        raise ValueError("Unknown token for decoding: " + msg)     # IllegalArgumentException
+    if rc == N.JTK_ERR_BAD_RANK_FILE:
+        raise RuntimeError(msg)                                    # IllegalStateException
+    raise EncodingError(rc, msg)
+
+
+class EncodingResult:
+    """api/EncodingResult.java"""
+
+    def __init__(self, tokens, truncated):
+        self.tokens = tokens
+        self.truncated = truncated
+
+    def get_tokens(self):
+        return self.tokens
+
+    def is_truncated(self):
+        return self.truncated
+
+    getTokens = get_tokens
+    isTruncated = is_truncated
+
+    def __repr__(self):
+        return "EncodingResult{tokens=%r, truncated=%s}" % (self.tokens, str(self.truncated).lower())
+
+
+class BatchResult:
+    """Packed result of a batch encode: tokens[int32], tok_off[int64, n_docs+1], status[int32, n_docs]."""
+
+    def __init__(self, tokens, tok_off, status):
+        self.tokens = tokens
+        self.tok_off = tok_off
+        self.status = status
+
+    def doc(self, d):
+        return self.tokens[self.tok_off[d]:self.tok_off[d + 1]]
+
+    def __len__(self):
+        return len(self.tok_off) - 1
+
+
+class Batch:
+    """One caller thread's stream + device scratch (jtk_batch)."""
+
+    def __init__(self, encoding):
+        self.encoding = encoding
+        h = C.c_void_p()
+        _check(N.lib().jtk_batch_create(encoding._h, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().jtk_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def encode_host(self, text_u8, doc_off, ordinary=False):
+        text_u8 = np.ascontiguousarray(text_u8, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+        nt = C.c_int64(0)
+        _check(N.lib().jtk_batch_encode(self._h, text_u8.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1,
+                                        N.JTK_ENCODE_ORDINARY if ordinary else 0, C.byref(nt)))
+        return nt.value
+
+    def encode_device(self, d_text_ptr, d_doc_off_ptr, n_docs, n_bytes, ordinary=False, stream=None, sync=True):
+        nt = C.c_int64(0)
+        _check(N.lib().jtk_batch_encode_device(self._h, d_text_ptr, d_doc_off_ptr, n_docs, n_bytes,
+                                               N.JTK_ENCODE_ORDINARY if ordinary else 0, stream,
+                                               C.byref(nt) if sync else None))
+        return nt.value if sync else None
+
+    def result(self):
+        nt, nd, ws = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        _check(N.lib().jtk_batch_result(self._h, C.byref(nt), C.byref(nd), C.byref(ws)))
+        return nt.value, nd.value, ws.value
+
+    def fetch(self):
+        nt, nd, _ = self.result()
+        tokens = np.empty(max(nt, 1), dtype=np.int32)
+        tok_off = np.empty(nd + 1, dtype=np.int64)
+        status = np.zeros(max(nd, 1), dtype=np.int32)
+        _check(N.lib().jtk_batch_fetch(self._h, tokens.ctypes.data, nt, tok_off.ctypes.data, status.ctypes.data))
+        return BatchResult(tokens[:nt], tok_off, status[:nd])
+
+    def device_result(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(N.lib().jtk_batch_device_result(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_profiling(self, on=True):
+        _check(N.lib().jtk_batch_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = C.c_int(0)
+        _check(N.lib().jtk_batch_kernel_times(self._h, names, ms, 16, C.byref(n)))
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+    def encode_one(self, text, ordinary, max_tokens):
+        if text is None:
+            return [], False
+        b = text if isinstance(text, (bytes, bytearray)) else text.encode("utf-8")
+        cap = len(b) + 1
+        out = np.empty(cap, dtype=np.int32)
+        nt = C.c_int64(0)
+        tr = C.c_int(0)
+        _check(N.lib().jtk_encode(self._h, bytes(b), len(b), N.JTK_ENCODE_ORDINARY if ordinary else 0,
+                                  -1 if max_tokens is None else int(max_tokens), out.ctypes.data, cap,
+                                  C.byref(nt), C.byref(tr)))
+        return out[:nt.value].tolist(), bool(tr.value)
+
+
+class HipEncoding:
+    """GPU-backed `Encoding` (reference GptBytePairEncoding.java:18 is the class this replaces)."""
+
+    def __init__(self, name, pattern_kind, tiktoken_bytes, special_tokens, device=0):
+        lits = [k.encode("utf-8") for k in special_tokens]
+        arr = (C.c_char_p * max(len(lits), 1))(*lits)
+        ids = (C.c_int32 * max(len(lits), 1))(*special_tokens.values())
+        h = C.c_void_p()
+        _check(N.lib().jtk_encoding_create(name.encode("utf-8"), pattern_kind, tiktoken_bytes, len(tiktoken_bytes),
+                                           arr, ids, len(lits), device, C.byref(h)))
+        self._h = h
+        self._name = name
+        self._batch = None
+
+    def close(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+        if getattr(self, "_h", None):
+            N.lib().jtk_encoding_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def new_batch(self):
+        return Batch(self)
+
+    def _b(self):
+        if self._batch is None:
+            self._batch = Batch(self)
+        return self._batch
+
+    # ---- api/Encoding.java ---------------------------------------------------------------------------
+    def encode(self, text, max_tokens=None):                       # Encoding.java:29,61
+        toks, tr = self._b().encode_one(text, False, max_tokens)
+        return toks if max_tokens is None else EncodingResult(toks, tr)
+
+    def encode_ordinary(self, text, max_tokens=None):              # :80,107
+        toks, tr = self._b().encode_one(text, True, max_tokens)
+        return toks if max_tokens is None else EncodingResult(toks, tr)
+
+    def count_tokens(self, text):                                  # :127
+        return len(self.encode(text))
+
+    def count_tokens_ordinary(self, text):                         # :147
+        return len(self.encode_ordinary(text))
+
+    def decode_bytes(self, tokens):                                # :181
+        ids = np.ascontiguousarray(tokens, dtype=np.int32)
+        n = C.c_int64(0)
+        _check(N.lib().jtk_decode(self._h, ids.ctypes.data, len(ids), None, 0, C.byref(n)))
+        out = np.empty(max(n.value, 1), dtype=np.uint8)
+        _check(N.lib().jtk_decode(self._h, ids.ctypes.data, len(ids), out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def decode(self, tokens):                                      # :164  new String(bytes, UTF_8)
+        return self.decode_bytes(tokens).decode("utf-8", errors="replace")
+
+    def get_name(self):                                            # :189
+        return self._name
+
+    encodeOrdinary = encode_ordinary
+    countTokens = count_tokens
+    countTokensOrdinary = count_tokens_ordinary
+    decodeBytes = decode_bytes
+    getName = get_name
+
+    # ---- batch -----------------------------------------------------------------------------------------
+    def encode_batch(self, texts, ordinary=False):
+        """List of str/bytes -> BatchResult (one jtk_batch_encode call)."""
+        bs = [t if isinstance(t, (bytes, bytearray)) else t.encode("utf-8") for t in texts]
+        doc_off = np.zeros(len(bs) + 1, dtype=np.int64)
+        if bs:
+            np.cumsum([len(b) for b in bs], out=doc_off[1:])
+        text = np.frombuffer(b"".join(bs), dtype=np.uint8) if doc_off[-1] else np.zeros(0, dtype=np.uint8)
+        return self.encode_batch_packed(text, doc_off, ordinary)
+
+    def encode_batch_packed(self, text_u8, doc_off, ordinary=False):
+        b = self._b()
+        b.encode_host(text_u8, doc_off, ordinary)
+        return b.fetch()
+
+    def vocab_size(self):
+        return N.lib().jtk_encoding_vocab_size(self._h)
+
+    def pair_count(self):
+        return N.lib().jtk_encoding_pair_count(self._h)

@@ -1,0 +1,90 @@
+// jtk_hostsim.cpp -- TEST INFRASTRUCTURE.  Runs the product's host/device-shared inline logic
+// (jtk_split_rules.h, jtk_common.h) on the CPU so that the per-byte split rules can be checked against the oracle in the CPU-only test tier, where no GPU exists.
+// Nothing in the product loads this library.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../jtokkit_amd/csrc/jtk_common.h"
+#include "../../jtokkit_amd/csrc/jtk_split_rules.h"
+#include "../../jtokkit_amd/csrc/jtk_unicode_tables.h"
+
+namespace {
+struct Txt {
+    const uint8_t* t; int64_t n;
+    uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
+};
+struct Win {
+    const uint8_t* t; int64_t n; const uint8_t* cbv;
+    uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
+    uint32_t cb(int64_t p) const { return (p >= 0 && p < n) ? cbv[p] : (uint32_t)JTK_CB_DS; }
+};
+}
+
+extern "C" {
+
+// ms_out[n_bytes+1]: 1 where a piece starts (position n_bytes is the sentinel and always 1)
+int sim_split(int kind, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs, uint8_t* ms_out) {
+    JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};
+    std::vector<uint8_t> cb((size_t)n + 1);
+    Txt txt{text, n};
+    for (int64_t p = 0; p < n; p++) cb[p] = (uint8_t)jtk_class_byte(txt, u, p);
+    for (int64_t d = 0; d <= n_docs; d++) if (doc_off[d] < n) cb[doc_off[d]] |= JTK_CB_DS;
+    Win w{text, n, cb.data()};
+    for (int64_t p = 0; p <= n; p++) ms_out[p] = jtk_is_piece_start(w, p, kind) ? 1 : 0;
+    return 0;
+}
+
+uint32_t sim_class_byte(const uint8_t* text, int64_t n, int64_t p) {
+    JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};
+    Txt txt{text, n};
+    return jtk_class_byte(txt, u, p);
+}
+}
+
+// ---- rank tables + lane merge on the host -----------------------------------------------------------
+#include <string>
+#include "../../jtokkit_amd/csrc/jtk_merge_core.h"
+#include "../../jtokkit_amd/csrc/jtk_tables.h"
+
+extern "C" {
+void* sim_tables_create(const char* name, int kind, const uint8_t* data, size_t len, int* status) {
+    JtkHostTables* t = new JtkHostTables();
+    std::string err;
+    int rc = jtk_build_tables(name, kind, data, len, nullptr, nullptr, 0, *t, err);
+    if (status) *status = rc;
+    if (rc != 0) { fprintf(stderr, "sim_tables_create: %s\n", err.c_str()); delete t; return nullptr; }
+    return t;
+}
+void sim_tables_destroy(void* h) { delete (JtkHostTables*)h; }
+int64_t sim_tables_pairs(void* h) { return ((JtkHostTables*)h)->n_pairs; }
+int sim_tables_bits(void* h) { return (int)((JtkHostTables*)h)->pair_bits; }
+// average probe count over all stored keys
+double sim_tables_avg_probe(void* h) {
+    JtkHostTables* t = (JtkHostTables*)h;
+    const uint32_t mask = (1u << t->pair_bits) - 1;
+    double tot = 0; int64_t n = 0;
+    for (size_t s = 0; s < t->pair_slots.size(); s++) {
+        uint64_t v = t->pair_slots[s];
+        if (v == JTK_PAIR_EMPTY) continue;
+        uint64_t key = v >> 30;
+        uint32_t a = (uint32_t)(key >> JTK_ID_BITS), b = (uint32_t)(key & ((1u << JTK_ID_BITS) - 1));
+        uint32_t h0 = jtk_pair_hash(a, b, t->pair_bits);
+        tot += ((s - h0) & mask) + 1; n++;
+    }
+    return tot / (double)n;
+}
+// bytePairMerge of one piece (len <= 64) with the device's lane algorithm
+int sim_merge_piece(void* h, const uint8_t* piece, int len, int32_t* out) {
+    JtkHostTables* t = (JtkHostTables*)h;
+    if (len < 1 || len > 64) return -1;
+    uint32_t ids[64], rk[64];
+    for (int i = 0; i < len; i++) ids[i] = t->byte_rank[piece[i]];
+    JtkPairTable pt{t->pair_slots.data(), t->pair_bits};
+    jtk_merge_piece_lane(ids, rk, len, pt);
+    int n = 0;
+    for (int i = 0; i < len; i++) if (ids[i] != JTK_ID_DEAD) out[n++] = (int32_t)ids[i];
+    return n;
+}
+}

@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/jtokkit_amd.h), against
+  (1) the reference's golden CSV fixtures (reference/Cl100kBaseTestTest.java:21-111 and siblings),
+  (2) the CPU oracle (oracle/jtk_oracle.cpp) on seeded synthetic inputs, bit-exact token ids.
+Every test here needs a real MI355X (`-m gpu`).
+"""
+import random
+
+import numpy as np
+import pytest
+
+import golden_util
+import oracle_lib
+import regex_crosscheck as rc
+
+pytestmark = pytest.mark.gpu
+
+NAMES = golden_util.ENCODING_NAMES
+
+
+@pytest.fixture(scope="module")
+def jt():
+    import jtokkit_amd
+    return jtokkit_amd
+
+
+def _assert_batch_equals_oracle(enc, oenc, texts, ordinary=True):
+    res = enc.encode_batch(texts, ordinary=ordinary)
+    assert len(res) == len(texts)
+    assert res.tok_off[0] == 0
+    bad = []
+    for d, t in enumerate(texts):
+        exp = oenc.encode_ordinary(t)
+        got = res.doc(d).tolist()
+        if got != exp:
+            bad.append((d, t, got, exp))
+    assert not bad, "first mismatch: %r" % (bad[0],)
+    assert res.tok_off[-1] == len(res.tokens)
+    return res
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_rows_batch(jt, name):
+    """All 423 rows of the reference's fixture as ONE batch: encode == expected (CsvFileSource tests)."""
+    enc = jt.get_encoding(name)
+    rows = golden_util.load_rows(name)
+    res = enc.encode_batch([r[0] for r in rows])
+    assert (res.status == 0).all()
+    for d, (inp, expected, _) in enumerate(rows):
+        assert res.doc(d).tolist() == expected, inp
+    res_o = enc.encode_batch([r[0] for r in rows], ordinary=True)
+    assert np.array_equal(res_o.tokens, res.tokens) and np.array_equal(res_o.tok_off, res.tok_off)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_rows_single_calls(jt, name):
+    """Per-call Encoding methods, as reference/Cl100kBaseTestTest.java:21-103 exercises them."""
+    enc = jt.get_encoding(name)
+    rows = golden_util.load_rows(name)
+    for inp, expected, expected10 in rows[::7] + rows[-2:]:
+        assert enc.encode(inp) == expected                                      # :21-29
+        assert enc.decode(enc.encode(inp)) == inp                               # :33-37
+        r = enc.encode(inp, 10)                                                 # :41-52
+        assert r.get_tokens() == expected10
+        assert r.is_truncated() == (len(expected) > len(expected10))
+        assert inp.startswith(enc.decode(r.get_tokens()))                       # :56-60
+        assert enc.encode_ordinary(inp) == expected                             # :64-72
+        r = enc.encode_ordinary(inp, 10)                                        # :76-88
+        assert r.get_tokens() == expected10 and r.is_truncated() == (len(expected) > len(expected10))
+        assert enc.count_tokens(inp) == len(expected)
+
+
+def test_known_answer_literals(jt):
+    enc = jt.get_encoding("cl100k_base")
+    assert enc.encode("hello world") == [15339, 1917]
+    assert enc.encode_ordinary("hello <|endoftext|> world") == [15339, 83739, 8862, 728, 428, 91, 29, 1917]
+    assert list(enc.decode_bytes([15339, 1917])) == [104, 101, 108, 108, 111, 32, 119, 111, 114, 108, 100]
+    assert enc.encode("This is a sample sentence.") == [2028, 374, 264, 6205, 11914, 13]
+    r = enc.encode("This is a sample sentence.", 3)
+    assert r.get_tokens() == [2028, 374, 264] and r.is_truncated()
+    r = enc.encode("I love \U0001f355", 4)
+    assert r.get_tokens() == [40, 3021] and r.is_truncated()
+    assert enc.get_name() == "cl100k_base"
+
+
+def test_special_tokens_and_errors(jt):
+    enc = jt.get_encoding("cl100k_base")
+    with pytest.raises(jt.UnsupportedOperationError):                           # GptBytePairEncoding.java:52-56
+        enc.encode("hello <|endoftext|> world")
+    with pytest.raises(jt.UnsupportedOperationError):
+        enc.count_tokens("x<|fim_middle|>")
+    s = "Hello<|endoftext|>, <|fim_prefix|> <|fim_middle|> world <|fim_suffix|> ! <|endofprompt|>"
+    for name in NAMES:                                                          # Cl100kBaseTestTest.java:105-111
+        e = jt.get_encoding(name)
+        assert e.decode(e.encode_ordinary(s)) == s
+    # batch: per-document status, other documents unaffected; literal split over two docs is not a hit
+    res = enc.encode_batch(["a <|endoftext|> b", "plain text", "<|endof", "text|>", "<|endofprompt|>"])
+    assert res.status.tolist() == [-2, 0, 0, 0, -2]
+    assert res.doc(1).tolist() == enc.encode("plain text")
+    # r50k knows only <|endoftext|>
+    r5 = jt.get_encoding("r50k_base")
+    assert r5.encode("a<|fim_prefix|>b") == oracle_lib.get("r50k_base").encode("a<|fim_prefix|>b")
+    with pytest.raises(ValueError):                                             # :313 IllegalArgumentException
+        enc.decode([100261])
+    assert enc.encode(None) == [] and enc.encode("") == []
+    r = enc.encode("", 10)
+    assert r.get_tokens() == [] and not r.is_truncated()
+    r = enc.encode("abc", 0)
+    assert r.get_tokens() == [] and r.is_truncated()
+
+
+def test_empty_and_ragged_batches(jt):
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    res = enc.encode_batch([])
+    assert len(res) == 0 and len(res.tokens) == 0 and res.tok_off.tolist() == [0]
+    res = enc.encode_batch(["", "", ""])
+    assert res.tok_off.tolist() == [0, 0, 0, 0]
+    texts = ["", "a", "", " ", "hello world", "", "\n", "", "x" * 70, "", ""]
+    _assert_batch_equals_oracle(enc, o, texts)
+
+
+@pytest.mark.parametrize("name,kind", [("cl100k_base", 1), ("r50k_base", 0), ("p50k_base", 0)])
+def test_fuzz_vs_oracle(jt, name, kind):
+    enc = jt.get_encoding(name)
+    o = oracle_lib.get(name)
+    rng = random.Random(4242 + kind)
+    for rnd in range(6):
+        texts = [rc.random_text(rng, rng.choice([4, 30, 200])) for _ in range(700)]
+        _assert_batch_equals_oracle(enc, o, texts)
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "r50k_base"])
+def test_long_runs_and_long_pieces(jt, name):
+    """Runs and pieces that cross LDS windows and tiles: digit / space / newline / letter / symbol runs
+    of 63..9000 characters, multi-byte runs, at varied alignments (the reference has no fixture > 146 B)."""
+    enc = jt.get_encoding(name)
+    o = oracle_lib.get(name)
+    texts = []
+    units = ["7", " ", "\n", "a", "=", "\r\n", "　", "é", "中", "٣", " \n", "ab ", "\U0001f355", "x1", "'s"]
+    for u in units:
+        for n in (63, 64, 65, 130, 257, 700, 4095, 4097, 4500, 8000):
+            k = max(1, n // len(u.encode()))
+            for pre in ("", "ab", "!", "x " * 2029):
+                for post in ("", "z", " z", "\n"):
+                    if n > 700 and (pre in ("ab", "!") or post in ("z", "\n")):
+                        continue
+                    texts.append(pre + u * k + post)
+    _assert_batch_equals_oracle(enc, o, texts)
+
+
+def test_piece_too_long_status(jt):
+    enc = jt.get_encoding("cl100k_base")
+    texts = ["ok text", "a" * 9000, "more ok"]
+    res = enc.encode_batch(texts)
+    assert res.status.tolist() == [0, -10, 0]
+    assert res.doc(0).tolist() == enc.encode("ok text") and res.doc(2).tolist() == enc.encode("more ok")
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "p50k_edit"])
+def test_synthetic_corpora_vs_oracle(jt, name):
+    """Seeded cfg-2-like (English) and cfg-3-like (mixed UTF-8) corpora, every document compared."""
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding(name)
+    o = oracle_lib.get(name)
+    for text, doc_off in (corpus.sentences(1000), corpus.english(3000), corpus.mixed(600)):
+        res = enc.encode_batch_packed(text, doc_off, ordinary=True)
+        exp_tok, exp_off = o.encode_batch(text, doc_off, threads=8)
+        assert np.array_equal(res.tok_off, exp_off)
+        assert np.array_equal(res.tokens, exp_tok)
+        assert (res.status == 0).all()
+
+
+def test_full_size_properties_cfg2(jt):
+    """BASELINE config 2 at full size (100k docs x ~1 KB): size-independent properties -- decode(tokens)
+    reproduces the input bytes exactly, offsets are monotone, a 1 % document sample equals the oracle."""
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = corpus.english(100000)
+    res = enc.encode_batch_packed(text, doc_off, ordinary=True)
+    assert (res.status == 0).all()
+    assert (np.diff(res.tok_off) >= 0).all() and res.tok_off[-1] == len(res.tokens)
+    assert enc.decode_bytes(res.tokens) == text.tobytes()
+    rng = np.random.default_rng(0)
+    for d in rng.choice(len(doc_off) - 1, 1000, replace=False):
+        doc = text[doc_off[d]:doc_off[d + 1]].tobytes()
+        assert res.doc(d).tolist() == o.encode_ordinary(doc)
+
+
+def test_device_entry_point_and_profiling(jt):
+    """jtk_batch_encode_device with torch-owned HBM buffers, as bench.py drives it."""
+    import torch
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = corpus.english(2000)
+    dev = torch.device("cuda:0")
+    d_text = torch.from_numpy(text).to(dev)
+    d_off = torch.from_numpy(doc_off).to(dev)
+    torch.cuda.synchronize()
+    b = enc.new_batch()
+    b.set_profiling(True)
+    nt = b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(doc_off) - 1, len(text), ordinary=True)
+    res = b.fetch()
+    exp_tok, exp_off = o.encode_batch(text, doc_off, threads=8)
+    assert nt == len(exp_tok) and np.array_equal(res.tokens, exp_tok) and np.array_equal(res.tok_off, exp_off)
+    times = b.kernel_times()
+    assert set(times) >= {"pretok_split", "bpe_merge", "pack"} and all(v >= 0 for v in times.values())
+    # results also readable in place
+    tp, op, sp = b.device_result()
+    assert tp and op and sp
+    b.close()
+
+
+def test_table_swap_back_to_back(jt):
+    """BASELINE config 5: r50k_base then p50k_base on the same corpus, tables cached per encoding."""
+    from jtokkit_amd import corpus
+    text, doc_off = corpus.mixed(300)
+    for name in ("r50k_base", "p50k_base", "r50k_base"):
+        enc = jt.get_encoding(name)
+        res = enc.encode_batch_packed(text, doc_off, ordinary=True)
+        exp_tok, exp_off = oracle_lib.get(name).encode_batch(text, doc_off, threads=8)
+        assert np.array_equal(res.tokens, exp_tok) and np.array_equal(res.tok_off, exp_off)
