@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- input MB/s of the cl100k_base batch encode path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path (mark_docs, pretok_split, bpe_merge, scan, pack -- every
+kernel of jtk_batch_encode_device) over one batch of synthetic documents that is already resident in
+HBM, ending with the total token count on the host; for N > 1 ranks each step also all-gathers the
+per-shard token totals over RCCL and stitches the shard's token offsets into global ones.
+
+N = 1 workload: BASELINE.json configs[1] -- cl100k_base, 100k synthetic English docs (~1 KB each).
+N > 1: weak scaling, every rank encodes its own 100k-doc shard (own seed); value = all ranks' input
+bytes / max-over-ranks time.  Launch: `python bench.py` or
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+
+
+class _DevArray:
+    """Zero-copy view of device memory for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16):
+    """Oracle (CPU restatement of GptBytePairEncoding.encode, kind "port") on the host cores, on a
+    bounded prefix of the same workload: one task per document on a fixed pool, as the reference's JMH
+    harness does (AbstractMultiThreadedBenchmark.java:35-45)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    enc = oracle_lib.get("cl100k_base")
+    # the GPU box allots 16 host cores per GPU (the machine itself shows far more)
+    cores = min(len(os.sched_getaffinity(0)), max_threads)
+    n_docs = len(doc_off) - 1
+
+    def run(nd, threads):
+        t0 = time.perf_counter()
+        enc.encode_batch(text, doc_off[:nd + 1], threads=threads, want_tokens=False)
+        return time.perf_counter() - t0
+
+    probe = min(n_docs, 400)
+    run(probe, cores)                                   # warm-up (page in the table)
+    dt = run(probe, cores)
+    rate = doc_off[probe] / dt
+    nd = int(min(n_docs, max(probe, np.searchsorted(doc_off, rate * budget_s))))
+    dt = run(nd, cores)
+    one = min(nd, max(probe, nd // cores))
+    dt1 = run(one, 1)
+    return {
+        "value": round(doc_off[nd] / 1e6 / dt, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+        "sample": "first %d docs (%.1f MB) of the same corpus, %d threads, one task per doc; "
+                  "1 thread on %d docs: %.2f MB/s" % (nd, doc_off[nd] / 1e6, cores, one, doc_off[one] / 1e6 / dt1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs-per-gpu", type=int, default=100000)
+    ap.add_argument("--workload", choices=["english", "mixed"], default="english")
+    ap.add_argument("--encoding", default="cl100k_base")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import jtokkit_amd
+    from jtokkit_amd import corpus
+
+    # ---- workload: this rank's shard, resident in HBM ----------------------------------------------
+    if args.workload == "english":
+        text, doc_off = corpus.english(args.docs_per_gpu, seed=2 + rank)
+        wl = "cl100k_base, %dk synthetic English docs (~1 KB each) per GPU" % (args.docs_per_gpu // 1000)
+    else:
+        text, doc_off = corpus.mixed(args.docs_per_gpu, seed=3 + rank)
+        wl = "%s, %dk mixed UTF-8 docs (emoji + CJK, ~4 KB each) per GPU" % (args.encoding, args.docs_per_gpu // 1000)
+    if args.encoding != "cl100k_base":
+        wl = wl.replace("cl100k_base", args.encoding)
+    n_docs, n_bytes = len(doc_off) - 1, int(doc_off[-1])
+    d_text = torch.from_numpy(text).to(dev)
+    d_off = torch.from_numpy(doc_off).to(dev)
+    enc = jtokkit_amd.get_encoding(args.encoding, device=local_rank)
+    batch = enc.new_batch()
+    batch.set_profiling(True)
+    stream = torch.cuda.current_stream().cuda_stream
+    totals = torch.zeros(world, dtype=torch.int64, device=dev)
+    mine = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        nt = batch.encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=True, stream=stream)
+        if world > 1:
+            # shard token totals -> every rank; exclusive prefix = this shard's global token offset
+            mine.fill_(nt)
+            dist.all_gather_into_tensor(totals, mine)
+            base = totals[:rank].sum()
+            _, off_ptr, _ = batch.device_result()
+            g_off = torch.as_tensor(_DevArray(off_ptr, n_docs + 1, "<i8"), device=dev)
+            g_off.add_(base)
+        return nt
+
+    for _ in range(args.warmup):
+        nt = step()
+    stage_ms = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nt = step()
+        for k, v in batch.kernel_times().items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    # max over ranks, sum of bytes
+    stats = torch.tensor([dt, float(n_bytes), float(nt), float(n_docs)], dtype=torch.float64, device=dev)
+    if world > 1:
+        allst = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allst, stats)
+        allst = torch.stack(allst).cpu().numpy()
+    else:
+        allst = stats.cpu().numpy()[None, :]
+    t_max = float(allst[:, 0].max())
+    total_bytes = float(allst[:, 1].sum())
+
+    if rank == 0:
+        steps = args.steps
+        for k in stage_ms:
+            stage_ms[k] /= steps
+        dom = max(stage_ms, key=stage_ms.get)
+        # algorithmic bytes of one batch: input once + int32 tokens once + both offset arrays
+        bytes_alg = n_bytes + 4 * nt + 16 * (n_docs + 1)
+        achieved = bytes_alg / (stage_ms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "input MB/s encoded (cl100k_base), bit-exact vs CPU oracle",
+            "value": round(total_bytes * steps / t_max / 1e6, 1),
+            "unit": "MB/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(t_max / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": wl, "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes, "tokens_per_gpu": int(nt),
+                       "sharding": "contiguous doc shards, one per GPU" + ("; RCCL all-gather of shard token totals" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(bytes_alg),
+                         "avg_launch_ms": round(stage_ms[dom], 4)},
+            "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(text, doc_off, max_threads=args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,26 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname
+    as /opt/rocm's); if this library pulled in the system copy first, a later `import torch` would load
+    a second runtime and fail with "No HIP GPUs are available".  So when torch is installed, its copy
+    is loaded first and libjtokkit_amd.so binds to it by soname, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -63,6 +83,7 @@ def lib():
             raise RuntimeError(
                 "jtokkit_amd: %s is missing -- build it with `make -C jtokkit_amd/csrc` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the library does not export the symbol
