@@ -85,7 +85,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     import jtokkit_amd
-    from jtokkit_amd import corpus
+    from jtokkit_amd import corpus, sharding
 
     # ---- workload: this rank's shard, resident in HBM ----------------------------------------------
     if args.workload == "english":
@@ -103,19 +103,15 @@ def main():
     batch = enc.new_batch()
     batch.set_profiling(True)
     stream = torch.cuda.current_stream().cuda_stream
-    totals = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step():
         nt = batch.encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=True, stream=stream)
         if world > 1:
             # shard token totals -> every rank; exclusive prefix = this shard's global token offset
-            mine.fill_(nt)
-            dist.all_gather_into_tensor(totals, mine)
-            base = totals[:rank].sum()
+            _, base = sharding.gather_shard_totals(nt, device=dev)
             _, off_ptr, _ = batch.device_result()
             g_off = torch.as_tensor(_DevArray(off_ptr, n_docs + 1, "<i8"), device=dev)
-            g_off.add_(base)
+            sharding.stitch_offsets(g_off, base)
         return nt
 
     for _ in range(args.warmup):

@@ -299,12 +299,4 @@ def mixed(n_docs, mean_bytes=4096, lo=256, hi=32768, seed=3):
     return _assemble(rng, streams, counts, mean_bytes, lo, hi)
 
 
-def shard_by_bytes(doc_off, world_size):
-    """Contiguous document ranges balanced by bytes: returns world_size+1 doc indices."""
-    total = int(doc_off[-1])
-    n_docs = len(doc_off) - 1
-    bounds = [0]
-    for r in range(1, world_size):
-        bounds.append(int(np.searchsorted(doc_off, total * r // world_size, side="left")))
-    bounds.append(n_docs)
-    return [min(max(b, 0), n_docs) for b in np.maximum.accumulate(bounds)]
+from .sharding import shard_by_bytes  # noqa: E402,F401  (kept here for callers of corpus.*)

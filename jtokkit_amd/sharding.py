@@ -1,0 +1,51 @@
+"""Multi-GPU sharding of a document batch.
+
+Documents are independent (every Encoding.encode call is a pure function of one string,
+reference GptBytePairEncoding.java:71-103), so a batch shards as contiguous document ranges balanced by
+bytes, one range per rank / GPU, each rank holding its own copy of the rank tables.  The only exchange
+is one all-gather of the per-shard token totals (RCCL over xGMI when the backend is "nccl"; gloo in
+the CPU tests); the exclusive prefix of the totals is the shard's global token offset.
+"""
+import numpy as np
+
+
+def shard_by_bytes(doc_off, world_size):
+    """Contiguous document ranges balanced by bytes: returns world_size + 1 document indices."""
+    doc_off = np.asarray(doc_off)
+    total = int(doc_off[-1])
+    n_docs = len(doc_off) - 1
+    bounds = [0]
+    for r in range(1, world_size):
+        bounds.append(int(np.searchsorted(doc_off, total * r // world_size, side="left")))
+    bounds.append(n_docs)
+    bounds = np.maximum.accumulate(np.clip(bounds, 0, n_docs))
+    return [int(b) for b in bounds]
+
+
+def local_shard(text, doc_off, rank, world_size):
+    """This rank's slice of a packed batch: (text_slice, doc_off rebased to 0, first_doc)."""
+    b = shard_by_bytes(doc_off, world_size)
+    d0, d1 = b[rank], b[rank + 1]
+    lo, hi = int(doc_off[d0]), int(doc_off[d1])
+    return text[lo:hi], np.asarray(doc_off[d0:d1 + 1]) - lo, d0
+
+
+def gather_shard_totals(n_tokens_local, group=None, device=None):
+    """All-gather of one int64 per rank; returns (totals[world], base offset of this rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.tensor([int(n_tokens_local)], dtype=torch.int64, device=device)
+    totals = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(totals, mine, group=group)
+    base = totals[:rank].sum()
+    return totals, base
+
+
+def stitch_offsets(local_tok_off, base):
+    """Global token offsets of this shard's documents = local offsets + the shard's base (in place for
+    torch tensors, a new array for numpy)."""
+    if isinstance(local_tok_off, np.ndarray):
+        return local_tok_off + int(base)
+    return local_tok_off.add_(base)

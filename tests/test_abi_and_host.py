@@ -1,0 +1,157 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads and exports every symbol
+include/jtokkit_amd.h declares, fails loudly without a GPU, and the host/device-shared logic (split
+rules, rank-table build, lane merge) agrees with the oracle when run on the CPU through the test shim
+tests/hostsim (no compute entry point of the product is called here)."""
+import ctypes as C
+import os
+import random
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util
+import oracle_lib
+import regex_crosscheck as rc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    so = os.path.join(ROOT, "jtokkit_amd", "libjtokkit_amd.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "jtokkit_amd", "csrc")])
+    from jtokkit_amd import _native
+    return _native
+
+
+def test_header_symbols_are_exported(native):
+    """Every function declared in include/jtokkit_amd.h is exported by the shared library and bound."""
+    hdr = open(os.path.join(ROOT, "include", "jtokkit_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(jtk_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = native.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "library does not export " + name
+        assert name in native.SIGNATURES, "python binding misses " + name
+    assert set(native.SIGNATURES) == declared
+
+
+def test_status_codes_match_header(native):
+    hdr = open(os.path.join(ROOT, "include", "jtokkit_amd.h")).read()
+    for name, val in re.findall(r"(JTK_[A-Z_0-9]+)\s*=\s*(-?\d+)u?", hdr):
+        if hasattr(native, name):
+            assert getattr(native, name) == int(val), name
+
+
+def test_fails_loudly_without_gpu(native):
+    """No CPU fallback: creating an encoding without a HIP device is an error, not a slow path."""
+    import jtokkit_amd
+    if native.lib().jtk_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(jtokkit_amd.EncodingError) as e:
+        jtokkit_amd.new_encoding("cl100k_base")
+    assert e.value.code == native.JTK_ERR_NO_DEVICE
+
+
+def test_bad_rank_file_is_rejected(native):
+    """EncodingFactory.java:150-152: a line without two fields -> IllegalStateException."""
+    lib = native.lib()
+    h = C.c_void_p()
+    bad = b"IQ== 0\nnot-a-valid-line\n"
+    rc_ = lib.jtk_encoding_create(b"x", 1, bad, len(bad), None, None, 0, 0, C.byref(h))
+    assert rc_ == native.JTK_ERR_BAD_RANK_FILE
+    missing_bytes = b"IQ== 0\nIg== 1\n"           # parses, but lacks most single bytes
+    rc_ = lib.jtk_encoding_create(b"x", 1, missing_bytes, len(missing_bytes), None, None, 0, 0, C.byref(h))
+    assert rc_ == native.JTK_ERR_UNSUPPORTED_TABLE
+    assert lib.jtk_encoding_create(b"x", 7, bad, len(bad), None, None, 0, 0, C.byref(h)) == native.JTK_ERR_INVALID_ARGUMENT
+
+
+# ---- host/device-shared logic on the CPU (tests/hostsim) -------------------------------------------------
+
+@pytest.fixture(scope="module")
+def sim():
+    d = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-C", d, "-s"])
+    L = C.CDLL(os.path.join(d, "libjtk_hostsim.so"))
+    L.sim_split.argtypes = [C.c_int, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sim_tables_create.restype = C.c_void_p
+    L.sim_tables_create.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.sim_tables_destroy.argtypes = [C.c_void_p]
+    L.sim_tables_pairs.restype = C.c_int64
+    L.sim_tables_pairs.argtypes = [C.c_void_p]
+    L.sim_merge_piece.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+    return L
+
+
+def _sim_pieces(sim, kind, docs):
+    bs = [d.encode("utf-8") for d in docs]
+    text = b"".join(bs)
+    off = np.zeros(len(bs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(b) for b in bs])
+    ms = np.zeros(len(text) + 1, dtype=np.uint8)
+    sim.sim_split(kind, text, len(text), off.ctypes.data, len(bs), ms.ctypes.data)
+    starts = np.nonzero(ms)[0].tolist()
+    return [text[starts[i]:starts[i + 1]] for i in range(len(starts) - 1)]
+
+
+@pytest.mark.parametrize("name,kind", [("cl100k_base", 1), ("r50k_base", 0)])
+def test_split_rules_match_oracle(sim, name, kind):
+    """jtk_split_rules.h (the per-byte form the pretok_split kernel evaluates) vs the oracle's sequential
+    backtracking matcher, on multi-document batches."""
+    enc = oracle_lib.get(name)
+    rng = random.Random(99 + kind)
+    for _ in range(4000):
+        docs = [rc.random_text(rng, 30) for _ in range(rng.randint(1, 4))]
+        exp = []
+        for d in docs:
+            exp += enc.split(d)
+        assert _sim_pieces(sim, kind, docs) == exp, docs
+    docs = [r[0] for r in golden_util.load_rows(name)]
+    exp = []
+    for d in docs:
+        exp += enc.split(d)
+    assert _sim_pieces(sim, kind, docs) == exp
+
+
+@pytest.mark.parametrize("name,pairs", [("cl100k_base", 233378), ("r50k_base", 108299), ("p50k_base", 108599)])
+def test_pair_table_and_lane_merge_match_oracle(sim, name, pairs):
+    """jtk_tables.cpp builds the (left id, right id) -> rank table (SURVEY appendix B counts); the lane
+    merge of jtk_merge_core.h on it equals the oracle's byte-string bytePairMerge."""
+    cfg = oracle_lib.ENCODINGS[name]
+    data = open(os.path.join(oracle_lib.DATA_DIR, cfg["file"]), "rb").read()
+    st = C.c_int(0)
+    h = sim.sim_tables_create(name.encode(), cfg["kind"], data, len(data), C.byref(st))
+    assert st.value == 0 and h
+    assert sim.sim_tables_pairs(h) == pairs
+    enc = oracle_lib.get(name)
+    out = np.zeros(64, dtype=np.int32)
+    rng = random.Random(5)
+    pieces = []
+    for inp, _, _ in golden_util.load_rows(name)[::3]:
+        pieces += [p for p in enc.split(inp) if len(p) <= 64]
+    alphabet = b"abcdefghijklmnopqrstuvwxyz ETAOIN.,!0123456789\xe4\xb8\xad\xe6\x96\x87\xf0\x9f\x8d\x95\n"
+    for _ in range(4000):
+        pieces.append(bytes(rng.choice(alphabet) for _ in range(rng.randint(1, 64))))
+    for p in pieces:
+        k = sim.sim_merge_piece(h, p, len(p), out.ctypes.data)
+        assert out[:k].tolist() == enc.merge_piece(p), p
+    sim.sim_tables_destroy(h)
+
+
+def test_corpus_generators_are_deterministic_and_valid():
+    from jtokkit_amd import corpus
+    a = corpus.english(300)
+    b = corpus.english(300)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    text, off = corpus.mixed(200)
+    assert off[0] == 0 and off[-1] == len(text) and (np.diff(off) > 0).all()
+    for d in range(len(off) - 1):
+        text[off[d]:off[d + 1]].tobytes().decode("utf-8")          # every document is well-formed UTF-8
+    t1, o1 = corpus.sentences(1000)
+    assert len(o1) == 1001 and t1.max() < 128
+    bounds = corpus.shard_by_bytes(off, 4)
+    assert bounds[0] == 0 and bounds[-1] == len(off) - 1 and bounds == sorted(bounds)
