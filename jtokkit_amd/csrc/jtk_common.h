@@ -68,6 +68,47 @@ JTK_HD uint32_t jtk_pair_lookup(const JtkPairTable& t, uint32_t a, uint32_t b) {
     }
 }
 
+// Both first probes are issued before either is examined, so the two loads overlap.
+JTK_HD void jtk_pair_lookup2(const JtkPairTable& t, uint32_t a1, uint32_t b1, bool want1, uint32_t a2, uint32_t b2,
+                             bool want2, uint32_t& r1, uint32_t& r2) {
+    const uint32_t mask = (1u << t.bits) - 1;
+    uint32_t h1 = jtk_pair_hash(a1, b1, t.bits), h2 = jtk_pair_hash(a2, b2, t.bits);
+    const uint64_t k1 = jtk_pair_key(a1, b1), k2 = jtk_pair_key(a2, b2);
+    uint64_t s1 = want1 ? t.slots[h1] : JTK_PAIR_EMPTY;
+    uint64_t s2 = want2 ? t.slots[h2] : JTK_PAIR_EMPTY;
+    for (;;) {
+        if ((s1 >> 30) == k1) { r1 = (uint32_t)(s1 & JTK_PAIR_RANK_MASK); break; }
+        if (s1 == JTK_PAIR_EMPTY) { r1 = JTK_RANK_NONE; break; }
+        h1 = (h1 + 1) & mask;
+        s1 = t.slots[h1];
+    }
+    for (;;) {
+        if ((s2 >> 30) == k2) { r2 = (uint32_t)(s2 & JTK_PAIR_RANK_MASK); break; }
+        if (s2 == JTK_PAIR_EMPTY) { r2 = JTK_RANK_NONE; break; }
+        h2 = (h2 + 1) & mask;
+        s2 = t.slots[h2];
+    }
+}
+
+// ---- whole-piece table for pieces of <= 8 bytes -------------------------------------------------------
+// GptBytePairEncoding.java:81-83: a piece that is itself a table entry encodes to that one token.
+// Key = the piece's bytes, little-endian in (lo, hi), zero padded, plus its length.  16-byte slots,
+// open addressing; len == 0 marks an empty slot.
+struct JtkTok8Slot {
+    uint32_t lo, hi, id, len;
+};
+struct JtkTok8Table {
+    const JtkTok8Slot* slots;
+    uint32_t bits;
+};
+JTK_HD uint32_t jtk_tok8_hash(uint32_t lo, uint32_t hi, uint32_t len, uint32_t bits) {
+    uint32_t h = lo * 0x9E3779B1u + (hi ^ (len << 27)) * 0x85EBCA77u;
+    h ^= h >> 16;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h >> (32 - bits);
+}
+
 // ---- Unicode class lookup ----------------------------------------------------------------------------
 struct JtkUcTables {
     const uint8_t* stage1;    // [0x1100]  cp >> 8 -> block

@@ -19,6 +19,8 @@ struct JtkDeviceTables {
     JtkUcTables uc;
     const uint32_t* byte_rank;   // [256]
     JtkPairTable pairs;
+    JtkTok8Table tok8;
+    const uint32_t* bp_rank;     // [65536]
     int kind;
     int n_specials;
     uint8_t special_len[JTK_MAX_SPECIALS];

@@ -128,7 +128,11 @@ struct GlobalText {
     __device__ uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
 };
 
-struct SplitWin {
+// Unbounded window: LDS where possible, else class bytes recomputed from global memory (runs longer
+// than the halo; slow, exact).
+struct SlowWin {
+    typedef int64_t idx_t;
+    static constexpr int kMaxWalk = 0;
     const uint8_t* cbv;      // LDS, index 0 = position lo
     const uint8_t* txv;      // LDS, index 0 = position lo - 4
     int64_t lo;
@@ -138,7 +142,6 @@ struct SplitWin {
         if (i >= 0 && i < S_TX) return txv[i];
         return (p >= 0 && p < n) ? gtext[p] : 0u;
     }
-    // Outside the LDS window (a run longer than the halo) the class byte is recomputed from global memory.
     __device__ uint32_t cb(int64_t p) const {
         const int64_t i = p - lo;
         if (i >= 0 && i < S_CB) return cbv[i];
@@ -150,11 +153,22 @@ struct SplitWin {
     }
 };
 
+// Window-relative 32-bit indices straight into LDS; run walks are capped inside the halo.
+struct FastWin {
+    typedef int idx_t;
+    static constexpr int kMaxWalk = SH - 8;
+    const uint8_t* cbv;      // index 0 = position lo
+    const uint8_t* txv;      // index 0 = position lo - 4
+    __device__ uint32_t byte(int i) const { return txv[i + 4]; }
+    __device__ uint32_t cb(int i) const { return cbv[i]; }
+};
+
 struct LdsText {
     const uint8_t* txv; int64_t tlo;
     __device__ uint32_t byte(int64_t p) const { return txv[p - tlo]; }
 };
 
+template <int KIND>
 __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[S_TX];
     __shared__ __attribute__((aligned(16))) uint8_t s_cb[S_CB];
@@ -194,10 +208,20 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
     }
     __syncthreads();
 
-    SplitWin win{s_cb, s_tx, lo, w.text, n, w.docmask, t.uc};
+    const FastWin fw{s_cb, s_tx};
     for (int r = 0; r < ST / 256; r++) {
-        const int64_t p = B + r * 256 + tid;
-        const bool ms = (p <= n) && jtk_is_piece_start(win, p, t.kind);
+        const int i = SH + r * 256 + tid;
+        const int64_t p = lo + i;
+        bool ms = false;
+        if (p <= n) {
+            bool unresolved = false;
+            ms = jtk_is_piece_start_t<KIND>(fw, i, unresolved);
+            if (unresolved) {
+                const SlowWin sw{s_cb, s_tx, lo, w.text, n, w.docmask, t.uc};
+                bool dummy = false;
+                ms = jtk_is_piece_start_t<KIND>(sw, p, dummy);
+            }
+        }
         const uint64_t bal = __ballot(ms);
         if ((tid & 63) == 0) {
             const int64_t wd = p >> 6;
@@ -211,6 +235,8 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
 // ---------------------------------------------------------------------------------------------------
 constexpr int MT = JTK_MERGE_TILE, MO = JTK_MERGE_OVER, MW = MT + MO;
 constexpr int M_BLK = MW / 64;                                      // 64-byte blocks in the window
+constexpr int M_TW = MT / 64;                                       // piecemask words of the tile proper
+static_assert(M_BLK <= 128 && M_TW <= 64, "scan helpers assume at most 128 blocks");
 
 // One wave merges one piece of any length held in LDS (ids/rk indexed by byte position of the piece).
 // Leftmost-minimum selection is a wave reduction on key = rank << 13 | position (positions < 8192),
@@ -255,17 +281,44 @@ __device__ void merge_piece_wave(uint32_t* ids, uint32_t* rk, int len, const Jtk
     }
 }
 
+// exclusive scan of cnt[0..n) (n <= 128) into pre[0..n], pre[n] = total; called by one whole wave
+__device__ __forceinline__ void wave_scan_small(const uint32_t* cnt, uint32_t* pre, int n) {
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    for (int c0 = 0; c0 < n; c0 += WAVE) {
+        const uint32_t c = (c0 + lane < n) ? cnt[c0 + lane] : 0u;
+        const uint32_t inc = wave_incl_scan(c);
+        if (c0 + lane < n) pre[c0 + lane] = base + inc - c;
+        base += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) pre[n] = base;
+}
+
+// up to 8 bytes of LDS text starting at (unaligned) offset s, little-endian, zero beyond len
+__device__ __forceinline__ void piece_key(const uint8_t* tx, int s, int len, uint32_t& lo, uint32_t& hi) {
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(tx);
+    const int a = s >> 2;
+    const uint32_t sh = (uint32_t)(s & 3);
+    const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2];
+    lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    if (len < 4) { lo &= (1u << (8 * len)) - 1u; hi = 0; }
+    else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
+}
+
 __global__ void __launch_bounds__(256) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tx[MW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tx[MW + 16];
     __shared__ uint32_t s_id[MW];
     __shared__ uint32_t s_rk[MW];
     __shared__ uint16_t s_plist[MT + 1];
+    __shared__ uint16_t s_hard[MT];            // piece indices that need bytePairMerge
     __shared__ uint64_t s_pm[M_BLK + 1];       // piecemask words of the window
     __shared__ uint64_t s_tm[M_BLK];           // token-start masks of the window
+    __shared__ uint32_t s_cnt[M_BLK];
     __shared__ uint32_t s_pre[M_BLK + 1];      // scanned counts
     __shared__ uint32_t s_brank[256];
-    __shared__ uint16_t s_medium[MT / 64];
-    __shared__ uint32_t s_nmedium;
+    __shared__ uint16_t s_medium[MT / 64 + 1];
+    __shared__ uint32_t s_nmedium, s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + MT (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -274,7 +327,7 @@ __global__ void __launch_bounds__(256) k_bpe_merge(JtkWork w, JtkDeviceTables t)
     const JtkPairTable pt = t.pairs;
 
     s_brank[tid] = t.byte_rank[tid];
-    for (int i = tid; i < MW / 4; i += 256) {
+    for (int i = tid; i < (MW + 16) / 4; i += 256) {
         const int64_t p = B + (int64_t)i * 4;
         uint32_t v = 0;
         if (p + 4 <= n) v = *reinterpret_cast<const uint32_t*>(w.text + p);
@@ -283,23 +336,20 @@ __global__ void __launch_bounds__(256) k_bpe_merge(JtkWork w, JtkDeviceTables t)
     }
     for (int i = tid; i < M_BLK + 1; i += 256) {
         const int64_t wd = (B >> 6) + i;
-        s_pm[i] = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
+        const uint64_t m = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
+        s_pm[i] = m;
+        if (i < M_TW) s_cnt[i] = (uint32_t)__popcll(m);
     }
     for (int i = tid; i < MW; i += 256) s_id[i] = JTK_ID_DEAD;
-    if (tid == 0) s_nmedium = 0;
+    if (tid == 0) { s_nmedium = 0; s_nhard = 0; }
     __syncthreads();
 
     // piece list of the tile: starts in [B, B+MT)
-    if (wv == 0) {
-        const uint32_t c = (uint32_t)__popcll(s_pm[lane]);            // MT/64 == 64 words
-        const uint32_t inc = wave_incl_scan(c);
-        s_pre[lane] = inc - c;
-        if (lane == 63) s_pre[64] = inc;
-    }
+    if (wv == 0) wave_scan_small(s_cnt, s_pre, M_TW);
     if (tid == 64) {
         // first piece start at or after B+MT: in the window's overhang words, else scan ahead
         int64_t pos = -1;
-        for (int i = MT / 64; i < M_BLK + 1 && pos < 0; i++)
+        for (int i = M_TW; i < M_BLK + 1 && pos < 0; i++)
             if (s_pm[i]) pos = B + (int64_t)i * 64 + jtk_ctz64(s_pm[i]);
         for (int64_t wd = (B >> 6) + M_BLK + 1; pos < 0 && wd < w.n_words; wd++) {
             const uint64_t m = w.piecemask[wd];
@@ -308,32 +358,85 @@ __global__ void __launch_bounds__(256) k_bpe_merge(JtkWork w, JtkDeviceTables t)
         s_next_after = (pos < 0) ? n : pos;
     }
     __syncthreads();
-    const int np = (int)s_pre[64];
-    for (int wd = wv; wd < MT / 64; wd += 4) {
+    const int np = (int)s_pre[M_TW];
+    for (int wd = wv; wd < M_TW; wd += 4) {
         const uint64_t m = s_pm[wd];
         if ((m >> lane) & 1ull) s_plist[s_pre[wd] + __popcll(m & lanemask_lt())] = (uint16_t)(wd * 64 + lane);
     }
     __syncthreads();
 
-    // short pieces: one lane each
+    // ---- pass 1: one lane per piece.  Pieces of <= 8 bytes that are table entries are that one token
+    // (GptBytePairEncoding.java:81-83); everything else is queued for bytePairMerge.  Four rounds of
+    // table probes are in flight per lane.
     const int64_t next_after = s_next_after;
-    for (int k = tid; k < np; k += 256) {
-        const int s = s_plist[k];
-        if (B + s >= n) continue;                                     // the end sentinel is not a piece
-        const int64_t e = (k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B);
-        const int64_t len = e - s;
-        if (len <= 64) {
-            for (int j = 0; j < (int)len; j++) s_id[s + j] = s_brank[s_tx[s + j]];
-            jtk_merge_piece_lane(&s_id[s], &s_rk[s], (int)len, pt);
-        } else if (e <= MW) {
-            s_medium[atomicAdd(&s_nmedium, 1u)] = (uint16_t)k;
-        } else {
-            const uint32_t slot = atomicAdd(w.long_count, 1u);
-            w.long_list[slot] = JtkLongPiece{B + s, (uint32_t)(len > 0x7FFFFFFF ? 0x7FFFFFFF : len), blockIdx.x};
+    const JtkTok8Slot* t8 = t.tok8.slots;
+    const uint32_t t8mask = (1u << t.tok8.bits) - 1u;
+    for (int k0 = 0; k0 < np; k0 += 4 * 256) {
+        int ps[4], pl[4];
+        uint32_t klo[4], khi[4], kh[4];
+        uint4 slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = k0 + u * 256 + tid;
+            ps[u] = -1; pl[u] = 0;
+            if (k < np) {
+                const int s = s_plist[k];
+                if (B + s < n) {                                          // the end sentinel is not a piece
+                    const int64_t e = (k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B);
+                    ps[u] = s;
+                    pl[u] = (e - s > 0x7FFF0000) ? 0x7FFF0000 : (int)(e - s);
+                }
+            }
+            if (ps[u] >= 0 && pl[u] <= 8) {
+                piece_key(s_tx, ps[u], pl[u], klo[u], khi[u]);
+                kh[u] = jtk_tok8_hash(klo[u], khi[u], (uint32_t)pl[u], t.tok8.bits);
+                slot[u] = *reinterpret_cast<const uint4*>(&t8[kh[u]]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bool hard = false;
+            if (ps[u] >= 0) {
+                const int s = ps[u], len = pl[u];
+                if (len <= 8) {
+                    uint4 sl = slot[u];
+                    uint32_t h = kh[u];
+                    uint32_t id = JTK_RANK_NONE;
+                    for (;;) {
+                        if (sl.w == (uint32_t)len && sl.x == klo[u] && sl.y == khi[u]) { id = sl.z; break; }
+                        if (sl.w == 0) break;
+                        h = (h + 1) & t8mask;
+                        sl = *reinterpret_cast<const uint4*>(&t8[h]);
+                    }
+                    if (id != JTK_RANK_NONE) s_id[s] = id; else hard = true;
+                } else if (len <= 64) {
+                    hard = true;
+                } else if ((int64_t)s + len <= MW) {
+                    s_medium[atomicAdd(&s_nmedium, 1u)] = (uint16_t)(k0 + u * 256 + tid);
+                } else {
+                    const uint32_t sl = atomicAdd(w.long_count, 1u);
+                    w.long_list[sl] = JtkLongPiece{B + s, (uint32_t)len, blockIdx.x};
+                }
+            }
+            const uint64_t bal = __ballot(hard);
+            if (bal) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_nhard, (uint32_t)__popcll(bal));
+                base = (uint32_t)__shfl((int)base, 0);
+                if (hard) s_hard[base + __popcll(bal & lanemask_lt())] = (uint16_t)(k0 + u * 256 + tid);
+            }
         }
     }
     __syncthreads();
 
+    // ---- pass 2: bytePairMerge, one lane per queued piece (<= 64 bytes)
+    const int nhard = (int)s_nhard;
+    for (int hI = tid; hI < nhard; hI += 256) {
+        const int k = s_hard[hI];
+        const int s = s_plist[k];
+        const int e = (k + 1 < np) ? (int)s_plist[k + 1] : (int)(next_after - B);
+        jtk_merge_piece_lane2(&s_id[s], &s_rk[s], &s_tx[s], e - s, pt, t.bp_rank, s_brank);
+    }
     // pieces of 65..window bytes: one wave each, cooperative leftmost-min
     const int nmed = (int)s_nmedium;
     for (int m = wv; m < nmed; m += 4) {
@@ -346,22 +449,13 @@ __global__ void __launch_bounds__(256) k_bpe_merge(JtkWork w, JtkDeviceTables t)
     }
     __syncthreads();
 
-    // pack the tile's tokens in position order
+    // ---- pack the tile's tokens in position order
     for (int blk = wv; blk < M_BLK; blk += 4) {
         const uint64_t bal = __ballot(s_id[blk * 64 + lane] != JTK_ID_DEAD);
-        if (lane == 0) s_tm[blk] = bal;
+        if (lane == 0) { s_tm[blk] = bal; s_cnt[blk] = (uint32_t)__popcll(bal); }
     }
     __syncthreads();
-    if (wv == 0) {
-        uint32_t c = (uint32_t)__popcll(s_tm[lane]);
-        uint32_t inc = wave_incl_scan(c);
-        s_pre[lane] = inc - c;
-        const uint32_t base64 = (uint32_t)__shfl((int)inc, 63);
-        uint32_t c2 = (lane < M_BLK - 64) ? (uint32_t)__popcll(s_tm[64 + lane]) : 0u;
-        uint32_t inc2 = wave_incl_scan(c2);
-        if (lane < M_BLK - 64) s_pre[64 + lane] = base64 + inc2 - c2;
-        if (lane == 63) s_pre[M_BLK] = base64 + inc2;
-    }
+    if (wv == 0) wave_scan_small(s_cnt, s_pre, M_BLK);
     __syncthreads();
     const int64_t fs = (np > 0) ? B + s_plist[0] : B;
     for (int blk = wv; blk < M_BLK; blk += 4) {
@@ -370,7 +464,7 @@ __global__ void __launch_bounds__(256) k_bpe_merge(JtkWork w, JtkDeviceTables t)
         if (lane == 0) {
             const int64_t wd = (B >> 6) + blk;
             if (m && wd < w.n_words) atomicOr((unsigned long long*)&w.tokmask[wd], m);
-            if (blk < MT / 64 && wd < w.n_words) w.blk_pre[wd] = (uint16_t)s_pre[blk];
+            if (blk < M_TW && wd < w.n_words) w.blk_pre[wd] = (uint16_t)s_pre[blk];
         }
     }
     if (tid == 0) { w.tile_cnt[blockIdx.x] = s_pre[M_BLK]; w.tile_fs[blockIdx.x] = fs; }
@@ -495,7 +589,8 @@ void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStr
 }
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     const int64_t tiles = (w.n_bytes + 1 + ST - 1) / ST;
-    hipLaunchKernelGGL(k_pretok_split, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
+    if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
+    else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_merge, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);

@@ -37,12 +37,14 @@
 
 #include "jtk_common.h"
 
-// Win must provide:  uint32_t cb(int64_t p)  (class byte, JTK_CB_DS set for p >= n_bytes) and
-//                    uint32_t byte(int64_t p).
+// Win must provide:  idx_t (integer type of positions), kMaxWalk (0 = unbounded run walks),
+//                    uint32_t cb(idx_t p)  (class byte, JTK_CB_DS set for p >= n_bytes) and uint32_t byte(idx_t p).
 // cb(p-1) is only ever read when !(cb(p) & JTK_CB_DS), i.e. p-1 lies in the same document.
+// With kMaxWalk > 0 a run walk longer than that sets `unresolved` (the caller re-evaluates the
+// position with an unbounded window); every other access stays within 8 bytes of p.
 
 template <class Win>
-JTK_HD bool jtk_other_is_match_start(const Win& w, int64_t j) {
+JTK_HD bool jtk_other_is_match_start(const Win& w, typename Win::idx_t j) {
     const uint32_t c = w.cb(j);
     if (c & JTK_CB_DS) return true;
     const uint32_t pb = w.cb(j - 1);
@@ -56,7 +58,7 @@ JTK_HD uint32_t jtk_fold_ascii(uint32_t b, bool ci) {
 // Length in bytes (2 or 3) of the contraction alternative matching at apostrophe position j, else 0.
 // Bytes after j must belong to the same document (checked through the DS flag).
 template <class Win>
-JTK_HD int jtk_contraction_len(const Win& w, int64_t j, bool ci) {
+JTK_HD int jtk_contraction_len(const Win& w, typename Win::idx_t j, bool ci) {
     if (w.byte(j) != '\'') return 0;
     if (w.cb(j + 1) & JTK_CB_DS) return 0;
     const uint32_t raw1 = w.byte(j + 1);
@@ -71,12 +73,13 @@ JTK_HD int jtk_contraction_len(const Win& w, int64_t j, bool ci) {
     return 0;
 }
 
-template <class Win>
-JTK_HD bool jtk_is_piece_start(const Win& w, int64_t p, int kind) {
+template <int KIND, class Win>
+JTK_HD bool jtk_is_piece_start_t(const Win& w, typename Win::idx_t p, bool& unresolved) {
+    typedef typename Win::idx_t idx_t;
     const uint32_t c = w.cb(p);
     if (c & JTK_CB_CONT) return false;
     if (c & JTK_CB_DS) return true;
-    const bool cl = (kind == JTK_PAT_CL100K);
+    constexpr bool cl = (KIND == JTK_PAT_CL100K);
     const uint32_t pb = w.cb(p - 1);
     const uint32_t cls = c & JTK_CB_CLS, pc = pb & JTK_CB_CLS;
 
@@ -85,14 +88,14 @@ JTK_HD bool jtk_is_piece_start(const Win& w, int64_t p, int kind) {
     if (cls == JTK_CLS_L) {
         if (pc == JTK_CLS_L) {
             // inside a letter run: only the end of a contraction piece starts a match here
-            if (!(w.cb(p - 1) & JTK_CB_DS) && jtk_contraction_len(w, p - 2, cl) == 2
-                && jtk_other_is_match_start(w, p - 2)) return true;
-            if (!(w.cb(p - 1) & JTK_CB_DS) && !(w.cb(p - 2) & JTK_CB_DS) && jtk_contraction_len(w, p - 3, cl) == 3
+            if (pb & JTK_CB_DS) return false;
+            if (jtk_contraction_len(w, p - 2, cl) == 2 && jtk_other_is_match_start(w, p - 2)) return true;
+            if (!(w.cb(p - 2) & JTK_CB_DS) && jtk_contraction_len(w, p - 3, cl) == 3
                 && jtk_other_is_match_start(w, p - 3)) return true;
             return false;
         }
         if (pc == JTK_CLS_O) {
-            int64_t j = p - 1;                                 // lead byte of the previous (O) char
+            idx_t j = p - 1;                                   // lead byte of the previous (O) char
             if (w.cb(j) & JTK_CB_CONT) { j--; if (w.cb(j) & JTK_CB_CONT) { j--; if (w.cb(j) & JTK_CB_CONT) j--; } }
             const bool prev_ms = jtk_other_is_match_start(w, j);
             if (cl) return !prev_ms;                           // glued as the one-char prefix, or contraction
@@ -105,17 +108,19 @@ JTK_HD bool jtk_is_piece_start(const Win& w, int64_t p, int kind) {
     if (cls == JTK_CLS_N) {
         if (!cl) return pc != JTK_CLS_N && !(pb & JTK_CB_SP);
         uint32_t cnt = 0;                                      // N chars before p in this run
-        int64_t k = p;
+        idx_t k = p;
+        int steps = 0;
         while (!(w.cb(k) & JTK_CB_DS) && (w.cb(k - 1) & JTK_CB_CLS) == JTK_CLS_N) {
             k--;
             cnt += (w.cb(k) & JTK_CB_CONT) ? 0u : 1u;
+            if (Win::kMaxWalk && ++steps >= Win::kMaxWalk) { unresolved = true; return false; }
         }
         return cnt % 3u == 0u;
     }
 
     // ---- whitespace ----
-    int64_t nx = p + 1;                                        // first byte after this char
-    while ((w.cb(nx) & (JTK_CB_CONT | JTK_CB_DS)) == JTK_CB_CONT) nx++;
+    idx_t nx = p + 1;                                          // first byte after this char
+    while ((w.cb(nx) & (JTK_CB_CONT | JTK_CB_DS)) == JTK_CB_CONT && nx < p + 4) nx++;
     const uint32_t nb = w.cb(nx);
     const bool last_in_run = (nb & JTK_CB_DS) || (nb & JTK_CB_CLS) != JTK_CLS_W;
     const bool followed_by_text = last_in_run && !(nb & JTK_CB_DS);
@@ -123,8 +128,12 @@ JTK_HD bool jtk_is_piece_start(const Win& w, int64_t p, int kind) {
     if (!cl) return run_start || followed_by_text;
 
     // walk back over the CR/LF bytes directly before p
-    int64_t k = p;
-    while (!(w.cb(k) & JTK_CB_DS) && (w.cb(k - 1) & JTK_CB_NL)) k--;
+    idx_t k = p;
+    int steps = 0;
+    while (!(w.cb(k) & JTK_CB_DS) && (w.cb(k - 1) & JTK_CB_NL)) {
+        k--;
+        if (Win::kMaxWalk && ++steps >= Win::kMaxWalk) { unresolved = true; return false; }
+    }
     bool at_run_start, after_other;
     if (w.cb(k) & JTK_CB_DS) { at_run_start = true; after_other = false; }
     else {
@@ -139,16 +148,25 @@ JTK_HD bool jtk_is_piece_start(const Win& w, int64_t p, int kind) {
     if (k == p && at_run_start) return true;                      // p == a == s
     if (k != p) {
         // previous byte is a CR/LF of this run at or after s: p == t iff no CR/LF remains in [p,e)
-        int64_t q = p;
+        idx_t q = p;
+        steps = 0;
         for (;;) {
             const uint32_t cq = w.cb(q);
             if ((cq & JTK_CB_DS) && q != p) return true;
             if ((cq & JTK_CB_CLS) != JTK_CLS_W) return true;
             if (cq & JTK_CB_NL) return false;
             q++;
+            if (Win::kMaxWalk && ++steps >= Win::kMaxWalk) { unresolved = true; return false; }
         }
     }
     return followed_by_text && !is_nl;
+}
+
+template <class Win>
+JTK_HD bool jtk_is_piece_start(const Win& w, typename Win::idx_t p, int kind) {
+    bool unresolved = false;
+    return kind == JTK_PAT_CL100K ? jtk_is_piece_start_t<JTK_PAT_CL100K>(w, p, unresolved)
+                                  : jtk_is_piece_start_t<JTK_PAT_R50K>(w, p, unresolved);
 }
 
 #endif

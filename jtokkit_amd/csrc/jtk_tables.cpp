@@ -133,8 +133,32 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         t.pair_slots[h] = (p.first << 30) | p.second;
     }
 
-    // The device path has no whole-piece shortcut (GptBytePairEncoding.java:81-83); that is only
-    // equivalent when merging any table token on its own yields exactly that token.
+    // whole-piece table (<= 8 bytes) and direct byte-pair table
+    t.bp_rank.assign(65536, JTK_RANK_NONE);
+    std::vector<const std::pair<const std::string, uint32_t>*> shorts;
+    for (auto& kv : t.bytes_to_id) {
+        if (kv.first.size() <= 8) shorts.push_back(&kv);
+        if (kv.first.size() == 2) t.bp_rank[((uint32_t)(uint8_t)kv.first[0] << 8) | (uint8_t)kv.first[1]] = kv.second;
+    }
+    t.n_tok8 = (int64_t)shorts.size();
+    uint32_t b8 = 10;
+    while ((1ull << b8) * 5 < shorts.size() * 8 + 64) b8++;            // load factor <= 0.625
+    t.tok8_bits = b8;
+    t.tok8.assign((size_t)1 << b8, JtkTok8Slot{0, 0, 0, 0});
+    for (auto* kv : shorts) {
+        uint32_t lo = 0, hi = 0;
+        const std::string& T = kv->first;
+        for (size_t k = 0; k < T.size(); k++) {
+            if (k < 4) lo |= (uint32_t)(uint8_t)T[k] << (8 * k); else hi |= (uint32_t)(uint8_t)T[k] << (8 * (k - 4));
+        }
+        uint32_t h = jtk_tok8_hash(lo, hi, (uint32_t)T.size(), b8);
+        while (t.tok8[h].len != 0) h = (h + 1) & ((1u << b8) - 1);
+        t.tok8[h] = JtkTok8Slot{lo, hi, kv->second, (uint32_t)T.size()};
+    }
+
+    // The shortcut is applied only to pieces of <= 8 bytes on the device; everything else goes through
+    // bytePairMerge.  That is only equivalent to GptBytePairEncoding.java:81-86 when merging any table
+    // token on its own yields exactly that token.
     JtkPairTable pt{t.pair_slots.data(), t.pair_bits};
     std::vector<uint32_t> ids, rk;
     for (auto& kv : t.bytes_to_id) {

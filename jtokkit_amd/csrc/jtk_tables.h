@@ -18,6 +18,10 @@ struct JtkHostTables {
     std::vector<uint8_t> id_present;
     std::vector<std::pair<std::string, int32_t>> specials;
     uint32_t byte_rank[256];                     // id of each single-byte token
+    std::vector<JtkTok8Slot> tok8;               // whole-piece table, pieces of <= 8 bytes
+    uint32_t tok8_bits = 0;
+    int64_t n_tok8 = 0;
+    std::vector<uint32_t> bp_rank;               // [65536] rank of the 2-byte token (b0 << 8 | b1), or NONE
     std::vector<uint64_t> pair_slots;            // open-addressed (left,right) -> rank table
     uint32_t pair_bits = 0;
     int64_t n_pairs = 0;

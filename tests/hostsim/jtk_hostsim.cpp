@@ -16,6 +16,8 @@ struct Txt {
     uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
 };
 struct Win {
+    typedef int64_t idx_t;
+    static constexpr int kMaxWalk = 0;
     const uint8_t* t; int64_t n; const uint8_t* cbv;
     uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
     uint32_t cb(int64_t p) const { return (p >= 0 && p < n) ? cbv[p] : (uint32_t)JTK_CB_DS; }
@@ -60,6 +62,24 @@ void* sim_tables_create(const char* name, int kind, const uint8_t* data, size_t 
 void sim_tables_destroy(void* h) { delete (JtkHostTables*)h; }
 int64_t sim_tables_pairs(void* h) { return ((JtkHostTables*)h)->n_pairs; }
 int sim_tables_bits(void* h) { return (int)((JtkHostTables*)h)->pair_bits; }
+// whole-piece table lookup (pieces of <= 8 bytes): id or -1
+int64_t sim_tok8_lookup(void* h, const uint8_t* piece, int len) {
+    JtkHostTables* t = (JtkHostTables*)h;
+    if (len < 1 || len > 8) return -1;
+    uint32_t lo = 0, hi = 0;
+    for (int k = 0; k < len; k++) { if (k < 4) lo |= (uint32_t)piece[k] << (8 * k); else hi |= (uint32_t)piece[k] << (8 * (k - 4)); }
+    uint32_t hh = jtk_tok8_hash(lo, hi, (uint32_t)len, t->tok8_bits);
+    int probes = 0;
+    for (;;) {
+        const JtkTok8Slot& s = t->tok8[hh];
+        probes++;
+        if (s.len == (uint32_t)len && s.lo == lo && s.hi == hi) return s.id;
+        if (s.len == 0) return -1;
+        hh = (hh + 1) & ((1u << t->tok8_bits) - 1);
+    }
+}
+int sim_tok8_bits(void* h) { return (int)((JtkHostTables*)h)->tok8_bits; }
+int64_t sim_tok8_count(void* h) { return ((JtkHostTables*)h)->n_tok8; }
 // average probe count over all stored keys
 double sim_tables_avg_probe(void* h) {
     JtkHostTables* t = (JtkHostTables*)h;
@@ -83,6 +103,10 @@ int sim_merge_piece(void* h, const uint8_t* piece, int len, int32_t* out) {
     for (int i = 0; i < len; i++) ids[i] = t->byte_rank[piece[i]];
     JtkPairTable pt{t->pair_slots.data(), t->pair_bits};
     jtk_merge_piece_lane(ids, rk, len, pt);
+    // the device's form (direct byte-pair table + paired lookups) must agree with the plain one
+    uint32_t ids2[64], rk2[64];
+    jtk_merge_piece_lane2(ids2, rk2, piece, len, pt, t->bp_rank.data(), t->byte_rank);
+    for (int i = 0; i < len; i++) if (ids[i] != ids2[i]) return -2;
     int n = 0;
     for (int i = 0; i < len; i++) if (ids[i] != JTK_ID_DEAD) out[n++] = (int32_t)ids[i];
     return n;

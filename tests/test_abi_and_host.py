@@ -84,6 +84,10 @@ def sim():
     L.sim_tables_pairs.restype = C.c_int64
     L.sim_tables_pairs.argtypes = [C.c_void_p]
     L.sim_merge_piece.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+    L.sim_tok8_lookup.restype = C.c_int64
+    L.sim_tok8_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.sim_tok8_count.restype = C.c_int64
+    L.sim_tok8_count.argtypes = [C.c_void_p]
     return L
 
 
@@ -138,7 +142,18 @@ def test_pair_table_and_lane_merge_match_oracle(sim, name, pairs):
         pieces.append(bytes(rng.choice(alphabet) for _ in range(rng.randint(1, 64))))
     for p in pieces:
         k = sim.sim_merge_piece(h, p, len(p), out.ctypes.data)
-        assert out[:k].tolist() == enc.merge_piece(p), p
+        assert k >= 0 and out[:k].tolist() == enc.merge_piece(p), p
+    # whole-piece table: a hit iff the piece (<= 8 bytes) is a table entry, and then it is that entry's rank
+    import base64
+    table = {}
+    for line in data.split(b"\n"):
+        if line:
+            tok, rank = line.split()
+            table[base64.b64decode(tok)] = int(rank)
+    assert sim.sim_tok8_count(h) == sum(1 for t in table if len(t) <= 8)
+    for p in pieces + [t for t in list(table)[::17] if len(t) <= 8]:
+        if len(p) <= 8:
+            assert sim.sim_tok8_lookup(h, p, len(p)) == table.get(p, -1), p
     sim.sim_tables_destroy(h)
 
 
