@@ -42,8 +42,8 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-constexpr int N_STAGES = 7;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "bpe_merge",
+constexpr int N_STAGES = 8;
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge",
                                            "bpe_merge_long", "tile_scan", "pack"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -63,8 +63,9 @@ struct jtk_batch {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;
     DevBuf in_text, in_off;          // staging for the host-buffer entry point
-    DevBuf zeroed;                   // docmask | tokmask | status | result | long_count
-    DevBuf piecemask, blk_pre, tmp_tok, tile_cnt, tile_fs, tile_off, long_list, tokens, tok_off;
+    DevBuf zeroed;                   // docmask | status | result | list counters
+    DevBuf piecemask, tokmask, blk_pre, tok_at, tile_cnt, tile_off, hard16, hard64, n_hard, mid_list, long_list,
+        tokens, tok_off;
     JtkResult* host_result = nullptr;   // pinned
     JtkWork work{};
     bool have_result = false, synced = false;
@@ -184,8 +185,9 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->enc->device);
     (void)hipStreamSynchronize(b->stream);
-    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->blk_pre, &b->tmp_tok, &b->tile_cnt,
-                      &b->tile_fs, &b->tile_off, &b->long_list, &b->tokens, &b->tok_off};
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->tokmask, &b->blk_pre, &b->tok_at,
+                      &b->tile_cnt, &b->tile_off, &b->hard16, &b->hard64, &b->n_hard, &b->mid_list, &b->long_list,
+                      &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
     if (b->ev_ok) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
     if (b->host_result) (void)hipHostFree(b->host_result);
@@ -221,33 +223,42 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.n_bytes = n_bytes;
     w.n_docs = n_docs;
     w.n_words = (n_bytes + 1 + 63) / 64 + 2;
-    w.n_tiles = (n_bytes + 1 + JTK_MERGE_TILE - 1) / JTK_MERGE_TILE;
+    w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
 
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
-    const size_t zero_bytes = 2 * mask_bytes + status_bytes + 32;
+    const size_t zero_bytes = mask_bytes + status_bytes + 32;
+    const size_t nt = (size_t)w.n_tiles;
+    const size_t n_long_max = (size_t)n_bytes / 65 + 2;
     int rc;
     if ((rc = b->zeroed.ensure(zero_bytes)) || (rc = b->piecemask.ensure(mask_bytes)) ||
-        (rc = b->blk_pre.ensure((size_t)w.n_words * 2)) ||
-        (rc = b->tmp_tok.ensure(((size_t)n_bytes + 64) * 4)) ||
-        (rc = b->tile_cnt.ensure((size_t)w.n_tiles * 4)) || (rc = b->tile_fs.ensure((size_t)w.n_tiles * 8)) ||
-        (rc = b->tile_off.ensure(((size_t)w.n_tiles + 1) * 8)) ||
-        (rc = b->long_list.ensure((size_t)w.n_tiles * sizeof(JtkLongPiece))) ||
+        (rc = b->tokmask.ensure(mask_bytes)) || (rc = b->blk_pre.ensure((size_t)w.n_words * 2)) ||
+        (rc = b->tok_at.ensure(nt * JTK_TILE * 4)) ||
+        (rc = b->tile_cnt.ensure(nt * 4)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
+        (rc = b->hard16.ensure(nt * JTK_HARD16_CAP * 4)) || (rc = b->hard64.ensure(nt * JTK_HARD64_CAP * 4)) ||
+        (rc = b->n_hard.ensure(nt * 8)) ||
+        (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
+        (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
         (rc = b->tok_off.ensure(((size_t)n_docs + 1) * 8)))
         return rc;
     uint8_t* z = (uint8_t*)b->zeroed.p;
     w.docmask = (uint64_t*)z;
-    w.tokmask = (uint64_t*)(z + mask_bytes);
-    w.status = (int32_t*)(z + 2 * mask_bytes);
-    w.result = (JtkResult*)(z + 2 * mask_bytes + status_bytes);
-    w.long_count = (uint32_t*)(z + 2 * mask_bytes + status_bytes + 16);
+    w.status = (int32_t*)(z + mask_bytes);
+    w.result = (JtkResult*)(z + mask_bytes + status_bytes);
+    w.mid_count = (uint32_t*)(z + mask_bytes + status_bytes + 16);
+    w.long_count = (uint32_t*)(z + mask_bytes + status_bytes + 20);
     w.piecemask = (uint64_t*)b->piecemask.p;
+    w.tokmask = (uint64_t*)b->tokmask.p;
     w.blk_pre = (uint16_t*)b->blk_pre.p;
-    w.tmp_tok = (int32_t*)b->tmp_tok.p;
+    w.tok_at = (uint32_t*)b->tok_at.p;
     w.tile_cnt = (uint32_t*)b->tile_cnt.p;
-    w.tile_fs = (int64_t*)b->tile_fs.p;
     w.tile_off = (int64_t*)b->tile_off.p;
+    w.hard16 = (uint32_t*)b->hard16.p;
+    w.hard64 = (uint32_t*)b->hard64.p;
+    w.n_hard16 = (uint32_t*)b->n_hard.p;
+    w.n_hard64 = (uint32_t*)b->n_hard.p + nt;
+    w.mid_list = (JtkLongPiece*)b->mid_list.p;
     w.long_list = (JtkLongPiece*)b->long_list.p;
     w.tokens = (int32_t*)b->tokens.p;
     w.tok_off = (int64_t*)b->tok_off.p;
@@ -263,6 +274,8 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     if (!(flags & JTK_ENCODE_ORDINARY)) jtk_launch_special_check(w, enc->dt, s);
     mark();
     jtk_launch_pretok_split(w, enc->dt, s);
+    mark();
+    jtk_launch_piece_resolve(w, enc->dt, s);
     mark();
     jtk_launch_bpe_merge(w, enc->dt, s);
     mark();

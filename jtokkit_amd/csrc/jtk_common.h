@@ -132,8 +132,8 @@ JTK_HD uint32_t jtk_class_of_ascii(uint32_t b) {
 // Class byte of position p.  `T` supplies byte(p) (0 outside the buffer).  Input is assumed to be
 // well-formed UTF-8 (String.getBytes(UTF_8)); on malformed input the result is some class, never an
 // out-of-range access.
-template <class T>
-JTK_HD uint32_t jtk_class_byte(const T& txt, const JtkUcTables& u, int64_t p) {
+template <class T, class I>
+JTK_HD uint32_t jtk_class_byte(const T& txt, const JtkUcTables& u, I p) {
     const uint32_t b = txt.byte(p);
     if (b < 0x80u) {
         uint32_t cb = jtk_class_of_ascii(b);
@@ -141,7 +141,7 @@ JTK_HD uint32_t jtk_class_byte(const T& txt, const JtkUcTables& u, int64_t p) {
         if (b == 0x20u) cb |= JTK_CB_SP;
         return cb;
     }
-    int64_t lead = p;
+    I lead = p;
     uint32_t flags = 0;
     if ((b & 0xC0u) == 0x80u) {
         flags = JTK_CB_CONT;

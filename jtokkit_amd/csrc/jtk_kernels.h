@@ -9,9 +9,12 @@
 
 #define JTK_SPLIT_TILE 4096      // bytes per pretok_split workgroup
 #define JTK_SPLIT_HALO 64
-#define JTK_MERGE_TILE 4096      // bytes per bpe_merge workgroup (pieces are owned by the tile they start in)
-#define JTK_MERGE_OVER 256       // a piece may run this far past its tile and still be merged in LDS
-#define JTK_LONG_CAP 8192        // longest piece the long-piece kernel holds in LDS (= JTK_MAX_PIECE_BYTES)
+#define JTK_TILE 4096            // bytes per piece_resolve / pack workgroup; token counts are kept per tile
+#define JTK_HARD16_CAP 2048      // per tile: pieces of 2..16 bytes queued for bytePairMerge (>= JTK_TILE / 2)
+#define JTK_HARD64_CAP 256       // per tile: pieces of 17..64 bytes (>= JTK_TILE / 17)
+#define JTK_HARD_GROUP 4         // tiles whose queues one merge workgroup drains
+#define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
+#define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin (= JTK_MAX_PIECE_BYTES)
 #define JTK_MAX_SPECIALS 8
 #define JTK_SPECIAL_MAXLEN 32
 
@@ -29,14 +32,13 @@ struct JtkDeviceTables {
 
 struct JtkLongPiece {
     int64_t start;
-    uint32_t len;
-    uint32_t tile;
+    int64_t len;
 };
 
 struct JtkResult {
     int64_t n_tokens;
     int32_t worst_status;
-    uint32_t n_long;
+    uint32_t pad;
 };
 
 // Device-side working set of one encode call (all pointers into the batch's scratch).
@@ -46,16 +48,21 @@ struct JtkWork {
     int64_t n_bytes;
     int64_t n_docs;
     int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
-    int64_t n_tiles;        // merge tiles
+    int64_t n_tiles;
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)
     uint64_t* tokmask;      // bit p: a token starts at byte p
-    uint16_t* blk_pre;      // per 64-byte block: tokens its tile owns before the block
-    int32_t* tmp_tok;       // per tile: its tokens, packed from position tile_fs
-    uint32_t* tile_cnt;
-    int64_t* tile_fs;
+    uint16_t* blk_pre;      // per 64-byte block: tokens of its tile before the block
+    uint32_t* tok_at;       // per byte position: id of the token starting there, or JTK_ID_DEAD
+    uint32_t* tile_cnt;     // tokens starting in each tile
     int64_t* tile_off;      // exclusive scan of tile_cnt (n_tiles + 1)
-    JtkLongPiece* long_list;
+    uint32_t* hard16;       // [n_tiles][JTK_HARD16_CAP]  offset-in-tile | len << 12
+    uint32_t* hard64;       // [n_tiles][JTK_HARD64_CAP]
+    uint32_t* n_hard16;     // [n_tiles]
+    uint32_t* n_hard64;     // [n_tiles]
+    JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
+    JtkLongPiece* long_list;// longer pieces
+    uint32_t* mid_count;
     uint32_t* long_count;
     int32_t* status;        // per document
     int32_t* tokens;        // output, packed
@@ -66,6 +73,7 @@ struct JtkWork {
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);

@@ -14,6 +14,7 @@
 #include "jtk_kernels.h"
 
 #include "jtk_merge_core.h"
+#include "jtk_split_masks.h"
 #include "jtk_split_rules.h"
 
 namespace {
@@ -117,34 +118,27 @@ __global__ void __launch_bounds__(256) k_special_check(JtkWork w, JtkDeviceTable
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pretok_split
+// pretok_split: one lane per byte classifies, __ballot turns the predicates into 64-bit masks, and the
+// split rules are scalar bit algebra per 64-byte block (jtk_split_masks.h).  Each wave walks 16
+// consecutive blocks of its workgroup's 4 KiB tile, carrying the block-to-block state in registers.
 // ---------------------------------------------------------------------------------------------------
 constexpr int ST = JTK_SPLIT_TILE, SH = JTK_SPLIT_HALO;
-constexpr int S_CB = ST + 2 * SH;          // class bytes kept in LDS: [B-SH, B+ST+SH)
-constexpr int S_TX = S_CB + 8;             // text kept in LDS:        [B-SH-4, B+ST+SH+4)
+constexpr int S_WIN = ST + 2 * SH;         // window [B-SH, B+ST+SH)
+constexpr int S_TX = S_WIN + 8;            // text kept in LDS: [B-SH-4, B+ST+SH+4)
+static_assert(SH == 64, "one halo block on each side");
 
 struct GlobalText {
     const uint8_t* t; int64_t n;
     __device__ uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
 };
 
-// Unbounded window: LDS where possible, else class bytes recomputed from global memory (runs longer
-// than the halo; slow, exact).
+// Unbounded window over global memory (runs longer than the halo; rare, exact).
 struct SlowWin {
     typedef int64_t idx_t;
     static constexpr int kMaxWalk = 0;
-    const uint8_t* cbv;      // LDS, index 0 = position lo
-    const uint8_t* txv;      // LDS, index 0 = position lo - 4
-    int64_t lo;
     const uint8_t* gtext; int64_t n; const uint64_t* docmask; JtkUcTables uc;
-    __device__ uint32_t byte(int64_t p) const {
-        const int64_t i = p - (lo - 4);
-        if (i >= 0 && i < S_TX) return txv[i];
-        return (p >= 0 && p < n) ? gtext[p] : 0u;
-    }
+    __device__ uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? gtext[p] : 0u; }
     __device__ uint32_t cb(int64_t p) const {
-        const int64_t i = p - lo;
-        if (i >= 0 && i < S_CB) return cbv[i];
         if (p >= n || p < 0) return JTK_CB_DS;
         GlobalText g{gtext, n};
         uint32_t c = jtk_class_byte(g, uc, p);
@@ -153,28 +147,67 @@ struct SlowWin {
     }
 };
 
-// Window-relative 32-bit indices straight into LDS; run walks are capped inside the halo.
+struct LdsText {                            // index = window-relative position (0 = B - SH)
+    const uint8_t* txv;
+    __device__ uint32_t byte(int i) const { return txv[i + 4]; }
+};
+
+// Window-relative 32-bit indices, class bytes computed from the LDS text; run walks are capped inside the halo.
 struct FastWin {
     typedef int idx_t;
     static constexpr int kMaxWalk = SH - 8;
-    const uint8_t* cbv;      // index 0 = position lo
-    const uint8_t* txv;      // index 0 = position lo - 4
+    const uint8_t* txv; const uint64_t* dm; int64_t lo; int64_t n; JtkUcTables uc;
     __device__ uint32_t byte(int i) const { return txv[i + 4]; }
-    __device__ uint32_t cb(int i) const { return cbv[i]; }
+    __device__ uint32_t cb(int i) const {
+        const int64_t p = lo + i;
+        if (p >= n) return JTK_CB_DS;
+        LdsText lt{txv};
+        uint32_t c = jtk_class_byte(lt, uc, i);
+        if ((dm[i >> 6] >> (i & 63)) & 1ull) c |= JTK_CB_DS;
+        return c;
+    }
 };
 
-struct LdsText {
-    const uint8_t* txv; int64_t tlo;
-    __device__ uint32_t byte(int64_t p) const { return txv[p - tlo]; }
-};
+template <int KIND>
+__device__ __forceinline__ JtkBlk classify_block(const uint8_t* s_tx, const uint64_t* s_dm, int wb, int64_t lo, int64_t n,
+                                                 const JtkUcTables& uc) {
+    const int lane = threadIdx.x & 63;
+    const int i = wb * 64 + lane;
+    const int64_t p = lo + i;
+    uint32_t c = 0, raw = 0;
+    if (p >= n) c = JTK_CB_DS;
+    else if (p >= 0) {
+        raw = s_tx[i + 4];
+        LdsText lt{s_tx};
+        c = jtk_class_byte(lt, uc, i);
+        if ((s_dm[wb] >> lane) & 1ull) c |= JTK_CB_DS;
+    }
+    const uint32_t cls = c & JTK_CB_CLS;
+    const uint32_t f = (KIND == JTK_PAT_CL100K && (raw - 'A') < 26u) ? (raw | 0x20u) : raw;
+    JtkBlk k;
+    k.L = __ballot(cls == JTK_CLS_L);
+    k.N = __ballot(cls == JTK_CLS_N);
+    k.W = __ballot(cls == JTK_CLS_W);
+    k.CONT = __ballot((c & JTK_CB_CONT) != 0);
+    k.NL = __ballot((c & JTK_CB_NL) != 0);
+    k.SP = __ballot((c & JTK_CB_SP) != 0);
+    k.DS = __ballot((c & JTK_CB_DS) != 0);
+    k.AP = __ballot(raw == '\'');
+    k.S1 = __ballot(f == 's' || f == 't' || f == 'm' || f == 'd');
+    k.RV = __ballot(f == 'r' || f == 'v');
+    k.E = __ballot(f == 'e');
+    k.LL = __ballot(f == 'l');
+    k.C5 = __ballot(raw == 0xC5u);
+    k.BF = __ballot(raw == 0xBFu);
+    return k;
+}
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[S_TX];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cb[S_CB];
-    __shared__ uint64_t s_dm[S_CB / 64 + 1];
+    __shared__ uint64_t s_dm[S_WIN / 64 + 1];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t B = (int64_t)blockIdx.x * ST;
     const int64_t lo = B - SH, tlo = lo - 4;
     const int64_t n = w.n_bytes;
@@ -187,65 +220,334 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
         else for (int j = 0; j < 4; j++) { const int64_t q = p + j; if (q >= 0 && q < n) v |= (uint32_t)w.text[q] << (8 * j); }
         reinterpret_cast<uint32_t*>(s_tx)[i] = v;
     }
-    for (int i = tid; i < S_CB / 64 + 1; i += 256) {
-        const int64_t wd = (lo >> 6) + i;
-        s_dm[i] = (wd >= 0 && wd < w.n_words) ? w.docmask[wd] : 0ull;
+    if (tid < S_WIN / 64 + 1) {
+        const int64_t wd = (lo >> 6) + tid;
+        s_dm[tid] = (wd >= 0 && wd < w.n_words) ? w.docmask[wd] : 0ull;
     }
     __syncthreads();
 
-    // class byte of every window position
-    LdsText lt{s_tx, tlo};
-    for (int i = tid; i < S_CB; i += 256) {
-        const int64_t p = lo + i;
-        uint32_t c;
-        if (p < 0) c = 0;
-        else if (p >= n) c = JTK_CB_DS;
-        else {
-            c = jtk_class_byte(lt, t.uc, p);
-            if ((s_dm[i >> 6] >> (i & 63)) & 1ull) c |= JTK_CB_DS;
+    constexpr int BPW = ST / 64 / 4;                                  // blocks per wave
+    const int wb0 = 1 + wv * BPW;                                     // window block of the wave's first block
+    JtkBlk cu = classify_block<KIND>(s_tx, s_dm, wb0, lo, n, t.uc);
+    JtkSplitCarry cy;
+    {
+        const JtkBlk halo = classify_block<KIND>(s_tx, s_dm, wb0 - 1, lo, n, t.uc);
+        jtk_split_carry_from_halo<KIND>(halo, cu, cy);
+    }
+    for (int b = 0; b < BPW; b++) {
+        const int wb = wb0 + b;
+        const JtkBlk nx = classify_block<KIND>(s_tx, s_dm, wb + 1, lo, n, t.uc);
+        const uint32_t ncnt0 = cy.ncnt;
+        const bool nunk0 = cy.n_unknown;
+        uint64_t slow, nlanes;
+        const uint64_t ms = jtk_split_block<KIND>(cu, nx, cy, slow, nlanes);
+        bool v = (ms >> lane) & 1ull;
+        bool sl = (slow >> lane) & 1ull;
+        if (nlanes) {                                                 // cl100k digit runs: every third char
+            if ((nlanes >> lane) & 1ull) { bool s2 = false; v = jtk_split_n_lane(cu, ncnt0, nunk0, lane, s2); sl = sl || s2; }
         }
-        s_cb[i] = (uint8_t)c;
-    }
-    __syncthreads();
-
-    const FastWin fw{s_cb, s_tx};
-    for (int r = 0; r < ST / 256; r++) {
-        const int i = SH + r * 256 + tid;
+        const int i = wb * 64 + lane;
         const int64_t p = lo + i;
-        bool ms = false;
-        if (p <= n) {
-            bool unresolved = false;
-            ms = jtk_is_piece_start_t<KIND>(fw, i, unresolved);
-            if (unresolved) {
-                const SlowWin sw{s_cb, s_tx, lo, w.text, n, w.docmask, t.uc};
-                bool dummy = false;
-                ms = jtk_is_piece_start_t<KIND>(sw, p, dummy);
+        if (__ballot(sl)) {
+            if (sl) {
+                const FastWin fw{s_tx, s_dm, lo, n, t.uc};
+                bool unresolved = false;
+                v = jtk_is_piece_start_t<KIND>(fw, i, unresolved);
+                if (unresolved) {
+                    const SlowWin sw{w.text, n, w.docmask, t.uc};
+                    bool dummy = false;
+                    v = jtk_is_piece_start_t<KIND>(sw, p, dummy);
+                }
             }
         }
-        const uint64_t bal = __ballot(ms);
-        if ((tid & 63) == 0) {
+        const uint64_t bal = __ballot(v && p <= n);
+        if (lane == 0) {
             const int64_t wd = p >> 6;
             if (wd < w.n_words) w.piecemask[wd] = bal;
         }
+        cu = nx;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// bpe_merge
+// piece_resolve: piece list of a tile; pieces of <= 8 bytes that are table entries become that one
+// token (GptBytePairEncoding.java:81-83); every other piece is queued for bytePairMerge by length.
+// Writes tok_at for the tile (token id at hit positions, DEAD elsewhere) and the tile's hit count.
 // ---------------------------------------------------------------------------------------------------
-constexpr int MT = JTK_MERGE_TILE, MO = JTK_MERGE_OVER, MW = MT + MO;
-constexpr int M_BLK = MW / 64;                                      // 64-byte blocks in the window
-constexpr int M_TW = MT / 64;                                       // piecemask words of the tile proper
-static_assert(M_BLK <= 128 && M_TW <= 64, "scan helpers assume at most 128 blocks");
+constexpr int T = JTK_TILE;
+constexpr int TW = T / 64;                                          // mask words per tile
+static_assert(TW <= 64, "tile scans assume at most 64 mask words");
 
-// One wave merges one piece of any length held in LDS (ids/rk indexed by byte position of the piece).
-// Leftmost-minimum selection is a wave reduction on key = rank << 13 | position (positions < 8192),
+// exclusive scan of cnt[0..n) (n <= 128) into pre[0..n], pre[n] = total; called by one whole wave
+__device__ __forceinline__ void wave_scan_small(const uint32_t* cnt, uint32_t* pre, int n) {
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    for (int c0 = 0; c0 < n; c0 += WAVE) {
+        const uint32_t c = (c0 + lane < n) ? cnt[c0 + lane] : 0u;
+        const uint32_t inc = wave_incl_scan(c);
+        if (c0 + lane < n) pre[c0 + lane] = base + inc - c;
+        base += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) pre[n] = base;
+}
+
+// up to 8 bytes of LDS text starting at (unaligned) offset s, little-endian, zero beyond len
+__device__ __forceinline__ void piece_key(const uint8_t* tx, int s, int len, uint32_t& lo, uint32_t& hi) {
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(tx);
+    const int a = s >> 2;
+    const uint32_t sh = (uint32_t)(s & 3);
+    const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2];
+    lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    if (len < 4) { lo &= (1u << (8 * len)) - 1u; hi = 0; }
+    else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
+}
+
+__global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_id[T];
+    __shared__ uint16_t s_plist[T + 1];
+    __shared__ uint64_t s_pm[TW];
+    __shared__ uint32_t s_cnt[TW];
+    __shared__ uint32_t s_pre[TW + 1];
+    __shared__ uint32_t s_n16, s_n64, s_hits;
+    __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t tile = blockIdx.x;
+    const int64_t B = tile * T;
+    const int64_t n = w.n_bytes;
+
+    for (int i = tid; i < (T + 16) / 4; i += 256) {
+        const int64_t p = B + (int64_t)i * 4;
+        uint32_t v = 0;
+        if (p + 4 <= n) v = *reinterpret_cast<const uint32_t*>(w.text + p);
+        else for (int j = 0; j < 4; j++) { if (p + j < n) v |= (uint32_t)w.text[p + j] << (8 * j); }
+        reinterpret_cast<uint32_t*>(s_tx)[i] = v;
+    }
+    if (tid < TW) {
+        const int64_t wd = (B >> 6) + tid;
+        const uint64_t m = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
+        s_pm[tid] = m;
+        s_cnt[tid] = (uint32_t)__popcll(m);
+    }
+    for (int i = tid; i < T / 4; i += 256) reinterpret_cast<uint4*>(s_id)[i] = make_uint4(JTK_ID_DEAD, JTK_ID_DEAD, JTK_ID_DEAD, JTK_ID_DEAD);
+    if (tid == 0) { s_n16 = 0; s_n64 = 0; s_hits = 0; }
+    if (tid == 64) {
+        int64_t pos = -1;                                             // scan ahead for the next piece start
+        for (int64_t wd = (B >> 6) + TW; pos < 0 && wd < w.n_words; wd++) {
+            const uint64_t m = w.piecemask[wd];
+            if (m) pos = wd * 64 + jtk_ctz64(m);
+        }
+        s_next_after = (pos < 0) ? n : pos;
+    }
+    __syncthreads();
+    if (wv == 0) wave_scan_small(s_cnt, s_pre, TW);
+    __syncthreads();
+    const int np = (int)s_pre[TW];
+    for (int wd = wv; wd < TW; wd += 4) {
+        const uint64_t m = s_pm[wd];
+        if ((m >> lane) & 1ull) s_plist[s_pre[wd] + __popcll(m & lanemask_lt())] = (uint16_t)(wd * 64 + lane);
+    }
+    __syncthreads();
+
+    // one lane per piece, four rounds of table probes in flight per lane
+    const int64_t next_after = s_next_after;
+    const JtkTok8Slot* t8 = t.tok8.slots;
+    const uint32_t t8mask = (1u << t.tok8.bits) - 1u;
+    uint32_t* const h16 = w.hard16 + tile * JTK_HARD16_CAP;
+    uint32_t* const h64 = w.hard64 + tile * JTK_HARD64_CAP;
+    uint32_t my_hits = 0;
+    struct Probe { int s, len; uint32_t lo, hi, h, sx, sy, sz, sw; };
+    auto issue = [&](int k, Probe& pr) {
+        pr.s = -1; pr.len = 0;
+        if (k < np) {
+            const int s = s_plist[k];
+            if (B + s < n) {                                              // the end sentinel is not a piece
+                const int64_t len64 = ((k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B)) - s;
+                pr.s = s;
+                pr.len = len64 > 0x10000 ? 0x10000 : (int)len64;
+            }
+        }
+        if (pr.s >= 0 && pr.len <= 8) {
+            piece_key(s_tx, pr.s, pr.len, pr.lo, pr.hi);
+            pr.h = jtk_tok8_hash(pr.lo, pr.hi, (uint32_t)pr.len, t.tok8.bits);
+            const uint4 v = *reinterpret_cast<const uint4*>(&t8[pr.h]);
+            pr.sx = v.x; pr.sy = v.y; pr.sz = v.z; pr.sw = v.w;
+        }
+    };
+    auto resolve = [&](int k, const Probe& pr) {
+        bool q16 = false, q64 = false;
+        if (pr.s >= 0) {
+            const int s = pr.s, len = pr.len;
+            if (len <= 8) {
+                uint4 sl = make_uint4(pr.sx, pr.sy, pr.sz, pr.sw);
+                uint32_t h = pr.h;
+                uint32_t id = JTK_RANK_NONE;
+                for (;;) {
+                    if (sl.w == (uint32_t)len && sl.x == pr.lo && sl.y == pr.hi) { id = sl.z; break; }
+                    if (sl.w == 0) break;
+                    h = (h + 1) & t8mask;
+                    sl = *reinterpret_cast<const uint4*>(&t8[h]);
+                }
+                if (id != JTK_RANK_NONE) { s_id[s] = id; my_hits++; } else q16 = true;
+            } else if (len <= 16) {
+                q16 = true;
+            } else if (len <= 64) {
+                q64 = true;
+            } else {
+                const int64_t len64 = ((k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B)) - s;
+                if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
+                else w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
+            }
+        }
+        const uint32_t entry = (uint32_t)(pr.s & 4095) | ((uint32_t)pr.len << 12);
+        uint64_t bal = __ballot(q16);
+        if (bal) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_n16, (uint32_t)__popcll(bal));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (q16) h16[base + __popcll(bal & lanemask_lt())] = entry;
+        }
+        bal = __ballot(q64);
+        if (bal) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_n64, (uint32_t)__popcll(bal));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (q64) h64[base + __popcll(bal & lanemask_lt())] = entry;
+        }
+    };
+    for (int k0 = 0; k0 < np; k0 += 4 * 256) {
+        Probe p0, p1, p2, p3;
+        issue(k0 + tid, p0);
+        issue(k0 + 256 + tid, p1);
+        issue(k0 + 512 + tid, p2);
+        issue(k0 + 768 + tid, p3);
+        resolve(k0 + tid, p0);
+        resolve(k0 + 256 + tid, p1);
+        resolve(k0 + 512 + tid, p2);
+        resolve(k0 + 768 + tid, p3);
+    }
+    // hit count of the tile
+    for (int d = 32; d >= 1; d >>= 1) my_hits += (uint32_t)__shfl_xor((int)my_hits, d);
+    if (lane == 0 && my_hits) atomicAdd(&s_hits, my_hits);
+    __syncthreads();
+    for (int i = tid; i < T / 4; i += 256)
+        reinterpret_cast<uint4*>(w.tok_at + B)[i] = reinterpret_cast<const uint4*>(s_id)[i];
+    if (tid == 0) { w.tile_cnt[tile] = s_hits; w.n_hard16[tile] = s_n16; w.n_hard64[tile] = s_n64; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bpe_merge: bytePairMerge of the queued pieces, ONE LANE PER PIECE, drained densely: a workgroup takes
+// the queues of JTK_HARD_GROUP consecutive tiles so that (almost) every lane has a piece and many
+// dependent lookup chains are in flight per CU.  Parts' ids and pair ranks live in LDS, laid out
+// [slot][lane] so that any per-lane slot index is bank-conflict free.
+// ---------------------------------------------------------------------------------------------------
+template <int SLOTS, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
+    __shared__ uint32_t s_ids[SLOTS * THREADS];
+    __shared__ uint32_t s_rk[SLOTS * THREADS];
+    __shared__ uint32_t s_brank[256];
+    __shared__ uint32_t s_tc[JTK_HARD_GROUP + 1];
+    constexpr int G = JTK_HARD_GROUP;
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const uint32_t* list = (SLOTS == 16) ? w.hard16 : w.hard64;
+    const uint32_t* cnts = (SLOTS == 16) ? w.n_hard16 : w.n_hard64;
+    constexpr int CAP = (SLOTS == 16) ? JTK_HARD16_CAP : JTK_HARD64_CAP;
+
+    uint32_t pre[G + 1];                       // only ever indexed by unrolled constants
+    pre[0] = 0;
+#pragma unroll
+    for (int g = 0; g < G; g++) pre[g + 1] = pre[g] + ((g0 + g < w.n_tiles) ? cnts[g0 + g] : 0u);
+    const uint32_t total = pre[G];
+    if (total == 0) return;
+    for (int i = tid; i < 256; i += THREADS) s_brank[i] = t.byte_rank[i];
+    if (tid <= G) s_tc[tid] = 0;
+    __syncthreads();
+
+    uint32_t* const ids = s_ids + tid;
+    uint32_t* const rk = s_rk + tid;
+    const JtkPairTable pt = t.pairs;
+    for (uint32_t i = tid; i < total; i += THREADS) {
+        int g = 0;
+        uint32_t gbase = 0;
+#pragma unroll
+        for (int q = 1; q < G; q++) if (i >= pre[q]) { g = q; gbase = pre[q]; }
+        const uint32_t entry = list[(g0 + g) * CAP + (i - gbase)];
+        const int64_t pos = (g0 + g) * T + (entry & 4095u);
+        const int len = (int)(entry >> 12);
+        // stage the piece's bytes (aligned dwords) in the rk slots, then expand to ids / pair ranks
+        const uint32_t off = (uint32_t)(pos & 3);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(w.text + (pos - off));
+        constexpr int NDW = SLOTS / 4 + 1;
+#pragma unroll
+        for (int k = 0; k < NDW; k++)
+            if ((int)(k * 4) < (int)off + len) rk[k * THREADS] = src[k];
+        const uint8_t* rkb = reinterpret_cast<const uint8_t*>(rk);
+        uint32_t prev = rkb[(off >> 2) * THREADS * 4 + (off & 3)];
+        for (int j = 0; j + 1 < len; j++) {
+            const uint32_t o = off + j + 1;
+            const uint32_t cur = rkb[(o >> 2) * THREADS * 4 + (o & 3)];
+            ids[j * THREADS] = (prev << 8) | cur;                       // byte pair, expanded below
+            prev = cur;
+        }
+        ids[(len - 1) * THREADS] = prev << 8;
+        for (int j = 0; j < len; j++) {
+            const uint32_t bp = ids[j * THREADS];
+            rk[j * THREADS] = (j + 1 < len) ? t.bp_rank[bp] : JTK_RANK_NONE;   // :216-221, ranks of 2-byte tokens
+            ids[j * THREADS] = s_brank[bp >> 8];
+        }
+        uint64_t alive = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);
+        int ntok = len;
+        while (ntok > 1) {                                                                   // :223
+            uint32_t minr = JTK_RANK_NONE;
+            int mini = 0;
+            for (uint64_t m = alive; m;) {                                                   // :234-240
+                const int j = jtk_ctz64(m);
+                m &= m - 1;
+                const uint32_t r = rk[j * THREADS];
+                if (r < minr) { minr = r; mini = j; }
+            }
+            if (minr == JTK_RANK_NONE) break;                                                // :247,:261
+            const uint64_t above = alive & ~((2ull << mini) - 1ull);
+            const int nxt = jtk_ctz64(above);
+            const uint64_t above2 = above & (above - 1);
+            const uint64_t below = alive & ((1ull << mini) - 1ull);
+            const int nn = above2 ? jtk_ctz64(above2) : 0;
+            const int pv = below ? 63 - jtk_clz64(below) : 0;
+            uint32_t r1, r2;
+            jtk_pair_lookup2(pt, minr, above2 ? ids[nn * THREADS] : 0u, above2 != 0, below ? ids[pv * THREADS] : 0u, minr,
+                             below != 0, r1, r2);                                            // :254-257
+            if (below) rk[pv * THREADS] = r2;
+            ids[mini * THREADS] = minr;
+            rk[mini * THREADS] = r1;
+            alive &= ~(1ull << nxt);                                                         // :259
+            ntok--;
+        }
+        // tokens go to the byte positions their parts start at; count them per tile
+        const int64_t tile_end = (g0 + g + 1) * (int64_t)T;
+        uint32_t c0 = 0, c1 = 0;
+        for (uint64_t m = alive; m;) {
+            const int j = jtk_ctz64(m);
+            m &= m - 1;
+            w.tok_at[pos + j] = ids[j * THREADS];
+            if (pos + j < tile_end) c0++; else c1++;
+        }
+        atomicAdd(&s_tc[g], c0);
+        if (c1) atomicAdd(&s_tc[g + 1], c1);
+    }
+    __syncthreads();
+    if (tid <= G && s_tc[tid] && g0 + tid < w.n_tiles) atomicAdd(&w.tile_cnt[g0 + tid], s_tc[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bpe_merge_long: one wave per piece of 65..8192 bytes.  Every lane scans a stride of the parts;
+// leftmost-minimum selection is a wave reduction on key = rank << 13 | position (positions < 8192),
 // which orders by rank first and by position among equal ranks (GptBytePairEncoding.java:236).
+// ---------------------------------------------------------------------------------------------------
 __device__ void merge_piece_wave(uint32_t* ids, uint32_t* rk, int len, const JtkPairTable pt) {
     const int lane = threadIdx.x & 63;
-    for (int j = lane; j < len; j += WAVE)
-        rk[j] = (j + 1 < len) ? jtk_pair_lookup(pt, ids[j], ids[j + 1]) : JTK_RANK_NONE;
-    wave_lds_fence();
     for (;;) {
         uint32_t best = 0xFFFFFFFFu;
         for (int j = lane; j < len; j += WAVE) {
@@ -281,207 +583,16 @@ __device__ void merge_piece_wave(uint32_t* ids, uint32_t* rk, int len, const Jtk
     }
 }
 
-// exclusive scan of cnt[0..n) (n <= 128) into pre[0..n], pre[n] = total; called by one whole wave
-__device__ __forceinline__ void wave_scan_small(const uint32_t* cnt, uint32_t* pre, int n) {
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    for (int c0 = 0; c0 < n; c0 += WAVE) {
-        const uint32_t c = (c0 + lane < n) ? cnt[c0 + lane] : 0u;
-        const uint32_t inc = wave_incl_scan(c);
-        if (c0 + lane < n) pre[c0 + lane] = base + inc - c;
-        base += (uint32_t)__shfl((int)inc, 63);
-    }
-    if (lane == 0) pre[n] = base;
-}
-
-// up to 8 bytes of LDS text starting at (unaligned) offset s, little-endian, zero beyond len
-__device__ __forceinline__ void piece_key(const uint8_t* tx, int s, int len, uint32_t& lo, uint32_t& hi) {
-    const uint32_t* tw = reinterpret_cast<const uint32_t*>(tx);
-    const int a = s >> 2;
-    const uint32_t sh = (uint32_t)(s & 3);
-    const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2];
-    lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-    hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-    if (len < 4) { lo &= (1u << (8 * len)) - 1u; hi = 0; }
-    else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
-}
-
-__global__ void __launch_bounds__(256) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tx[MW + 16];
-    __shared__ uint32_t s_id[MW];
-    __shared__ uint32_t s_rk[MW];
-    __shared__ uint16_t s_plist[MT + 1];
-    __shared__ uint16_t s_hard[MT];            // piece indices that need bytePairMerge
-    __shared__ uint64_t s_pm[M_BLK + 1];       // piecemask words of the window
-    __shared__ uint64_t s_tm[M_BLK];           // token-start masks of the window
-    __shared__ uint32_t s_cnt[M_BLK];
-    __shared__ uint32_t s_pre[M_BLK + 1];      // scanned counts
-    __shared__ uint32_t s_brank[256];
-    __shared__ uint16_t s_medium[MT / 64 + 1];
-    __shared__ uint32_t s_nmedium, s_nhard;
-    __shared__ int64_t s_next_after;           // first piece start at or after B + MT (global position)
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t B = (int64_t)blockIdx.x * MT;
-    const int64_t n = w.n_bytes;
-    const JtkPairTable pt = t.pairs;
-
-    s_brank[tid] = t.byte_rank[tid];
-    for (int i = tid; i < (MW + 16) / 4; i += 256) {
-        const int64_t p = B + (int64_t)i * 4;
-        uint32_t v = 0;
-        if (p + 4 <= n) v = *reinterpret_cast<const uint32_t*>(w.text + p);
-        else for (int j = 0; j < 4; j++) { if (p + j < n) v |= (uint32_t)w.text[p + j] << (8 * j); }
-        reinterpret_cast<uint32_t*>(s_tx)[i] = v;
-    }
-    for (int i = tid; i < M_BLK + 1; i += 256) {
-        const int64_t wd = (B >> 6) + i;
-        const uint64_t m = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
-        s_pm[i] = m;
-        if (i < M_TW) s_cnt[i] = (uint32_t)__popcll(m);
-    }
-    for (int i = tid; i < MW; i += 256) s_id[i] = JTK_ID_DEAD;
-    if (tid == 0) { s_nmedium = 0; s_nhard = 0; }
-    __syncthreads();
-
-    // piece list of the tile: starts in [B, B+MT)
-    if (wv == 0) wave_scan_small(s_cnt, s_pre, M_TW);
-    if (tid == 64) {
-        // first piece start at or after B+MT: in the window's overhang words, else scan ahead
-        int64_t pos = -1;
-        for (int i = M_TW; i < M_BLK + 1 && pos < 0; i++)
-            if (s_pm[i]) pos = B + (int64_t)i * 64 + jtk_ctz64(s_pm[i]);
-        for (int64_t wd = (B >> 6) + M_BLK + 1; pos < 0 && wd < w.n_words; wd++) {
-            const uint64_t m = w.piecemask[wd];
-            if (m) pos = wd * 64 + jtk_ctz64(m);
-        }
-        s_next_after = (pos < 0) ? n : pos;
-    }
-    __syncthreads();
-    const int np = (int)s_pre[M_TW];
-    for (int wd = wv; wd < M_TW; wd += 4) {
-        const uint64_t m = s_pm[wd];
-        if ((m >> lane) & 1ull) s_plist[s_pre[wd] + __popcll(m & lanemask_lt())] = (uint16_t)(wd * 64 + lane);
-    }
-    __syncthreads();
-
-    // ---- pass 1: one lane per piece.  Pieces of <= 8 bytes that are table entries are that one token
-    // (GptBytePairEncoding.java:81-83); everything else is queued for bytePairMerge.  Four rounds of
-    // table probes are in flight per lane.
-    const int64_t next_after = s_next_after;
-    const JtkTok8Slot* t8 = t.tok8.slots;
-    const uint32_t t8mask = (1u << t.tok8.bits) - 1u;
-    for (int k0 = 0; k0 < np; k0 += 4 * 256) {
-        int ps[4], pl[4];
-        uint32_t klo[4], khi[4], kh[4];
-        uint4 slot[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int k = k0 + u * 256 + tid;
-            ps[u] = -1; pl[u] = 0;
-            if (k < np) {
-                const int s = s_plist[k];
-                if (B + s < n) {                                          // the end sentinel is not a piece
-                    const int64_t e = (k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B);
-                    ps[u] = s;
-                    pl[u] = (e - s > 0x7FFF0000) ? 0x7FFF0000 : (int)(e - s);
-                }
-            }
-            if (ps[u] >= 0 && pl[u] <= 8) {
-                piece_key(s_tx, ps[u], pl[u], klo[u], khi[u]);
-                kh[u] = jtk_tok8_hash(klo[u], khi[u], (uint32_t)pl[u], t.tok8.bits);
-                slot[u] = *reinterpret_cast<const uint4*>(&t8[kh[u]]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            bool hard = false;
-            if (ps[u] >= 0) {
-                const int s = ps[u], len = pl[u];
-                if (len <= 8) {
-                    uint4 sl = slot[u];
-                    uint32_t h = kh[u];
-                    uint32_t id = JTK_RANK_NONE;
-                    for (;;) {
-                        if (sl.w == (uint32_t)len && sl.x == klo[u] && sl.y == khi[u]) { id = sl.z; break; }
-                        if (sl.w == 0) break;
-                        h = (h + 1) & t8mask;
-                        sl = *reinterpret_cast<const uint4*>(&t8[h]);
-                    }
-                    if (id != JTK_RANK_NONE) s_id[s] = id; else hard = true;
-                } else if (len <= 64) {
-                    hard = true;
-                } else if ((int64_t)s + len <= MW) {
-                    s_medium[atomicAdd(&s_nmedium, 1u)] = (uint16_t)(k0 + u * 256 + tid);
-                } else {
-                    const uint32_t sl = atomicAdd(w.long_count, 1u);
-                    w.long_list[sl] = JtkLongPiece{B + s, (uint32_t)len, blockIdx.x};
-                }
-            }
-            const uint64_t bal = __ballot(hard);
-            if (bal) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&s_nhard, (uint32_t)__popcll(bal));
-                base = (uint32_t)__shfl((int)base, 0);
-                if (hard) s_hard[base + __popcll(bal & lanemask_lt())] = (uint16_t)(k0 + u * 256 + tid);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- pass 2: bytePairMerge, one lane per queued piece (<= 64 bytes)
-    const int nhard = (int)s_nhard;
-    for (int hI = tid; hI < nhard; hI += 256) {
-        const int k = s_hard[hI];
-        const int s = s_plist[k];
-        const int e = (k + 1 < np) ? (int)s_plist[k + 1] : (int)(next_after - B);
-        jtk_merge_piece_lane2(&s_id[s], &s_rk[s], &s_tx[s], e - s, pt, t.bp_rank, s_brank);
-    }
-    // pieces of 65..window bytes: one wave each, cooperative leftmost-min
-    const int nmed = (int)s_nmedium;
-    for (int m = wv; m < nmed; m += 4) {
-        const int k = s_medium[m];
-        const int s = s_plist[k];
-        const int e = (k + 1 < np) ? (int)s_plist[k + 1] : (int)(next_after - B);
-        for (int j = s + lane; j < e; j += WAVE) s_id[j] = s_brank[s_tx[j]];
-        wave_lds_fence();
-        merge_piece_wave(&s_id[s], &s_rk[s], e - s, pt);
-    }
-    __syncthreads();
-
-    // ---- pack the tile's tokens in position order
-    for (int blk = wv; blk < M_BLK; blk += 4) {
-        const uint64_t bal = __ballot(s_id[blk * 64 + lane] != JTK_ID_DEAD);
-        if (lane == 0) { s_tm[blk] = bal; s_cnt[blk] = (uint32_t)__popcll(bal); }
-    }
-    __syncthreads();
-    if (wv == 0) wave_scan_small(s_cnt, s_pre, M_BLK);
-    __syncthreads();
-    const int64_t fs = (np > 0) ? B + s_plist[0] : B;
-    for (int blk = wv; blk < M_BLK; blk += 4) {
-        const uint64_t m = s_tm[blk];
-        if ((m >> lane) & 1ull) w.tmp_tok[fs + s_pre[blk] + __popcll(m & lanemask_lt())] = (int32_t)s_id[blk * 64 + lane];
-        if (lane == 0) {
-            const int64_t wd = (B >> 6) + blk;
-            if (m && wd < w.n_words) atomicOr((unsigned long long*)&w.tokmask[wd], m);
-            if (blk < M_TW && wd < w.n_words) w.blk_pre[wd] = (uint16_t)s_pre[blk];
-        }
-    }
-    if (tid == 0) { w.tile_cnt[blockIdx.x] = s_pre[M_BLK]; w.tile_fs[blockIdx.x] = fs; }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// bpe_merge_long: pieces that leave their tile's window (always the last piece of the tile).
-// One 64-lane workgroup per piece, ids/ranks in LDS.
-// ---------------------------------------------------------------------------------------------------
+template <int CAP>
 __global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint32_t s_id[JTK_LONG_CAP];
-    __shared__ uint32_t s_rk[JTK_LONG_CAP];
+    __shared__ uint32_t s_id[CAP];
+    __shared__ uint32_t s_rk[CAP];
     const int lane = threadIdx.x;
-    const uint32_t cnt = *w.long_count;
+    const JtkLongPiece* list = (CAP == JTK_MID_CAP) ? w.mid_list : w.long_list;
+    const uint32_t cnt = (CAP == JTK_MID_CAP) ? *w.mid_count : *w.long_count;
     for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
-        const JtkLongPiece lp = w.long_list[i];
-        if (lp.len > JTK_LONG_CAP) {
+        const JtkLongPiece lp = list[i];
+        if (lp.len > CAP) {
             if (lane == 0) {
                 const int64_t d = find_doc(w.doc_off, w.n_docs, lp.start);
                 if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
@@ -489,28 +600,29 @@ __global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTable
             continue;
         }
         const int len = (int)lp.len;
-        for (int j = lane; j < len; j += WAVE) s_id[j] = t.byte_rank[w.text[lp.start + j]];
+        for (int j = lane; j < len; j += WAVE) {
+            const uint32_t b0 = w.text[lp.start + j];
+            s_id[j] = t.byte_rank[b0];
+            s_rk[j] = (j + 1 < len) ? t.bp_rank[(b0 << 8) | w.text[lp.start + j + 1]] : JTK_RANK_NONE;
+        }
         wave_lds_fence();
         merge_piece_wave(s_id, s_rk, len, t.pairs);
-        // append after the tile's own tokens, in position order
-        const int64_t out0 = w.tile_fs[lp.tile] + w.tile_cnt[lp.tile];
-        uint32_t total = 0;
         for (int base = 0; base < len; base += WAVE) {
             const int j = base + lane;
             const bool alive = j < len && s_id[j] != JTK_ID_DEAD;
+            if (alive) w.tok_at[lp.start + j] = s_id[j];
             const uint64_t bal = __ballot(alive);
-            if (alive) w.tmp_tok[out0 + total + __popcll(bal & lanemask_lt())] = (int32_t)s_id[j];
-            // token-start bits; the piece need not be 64-aligned, so split the ballot over two words
             if (lane == 0 && bal) {
                 const int64_t p0 = lp.start + base;
-                const int sh = (int)(p0 & 63);
-                atomicOr((unsigned long long*)&w.tokmask[p0 >> 6], bal << sh);
-                if (sh) atomicOr((unsigned long long*)&w.tokmask[(p0 >> 6) + 1], bal >> (64 - sh));
+                const int64_t tl = p0 / T;
+                const int64_t room = (tl + 1) * (int64_t)T - p0;          // positions of this chunk in tile tl
+                const uint64_t lo_mask = room >= 64 ? ~0ull : ((1ull << room) - 1ull);
+                const uint32_t c0 = (uint32_t)__popcll(bal & lo_mask), c1 = (uint32_t)__popcll(bal & ~lo_mask);
+                if (c0) atomicAdd(&w.tile_cnt[tl], c0);
+                if (c1) atomicAdd(&w.tile_cnt[tl + 1], c1);
             }
-            total += (uint32_t)__popcll(bal);
         }
         wave_lds_fence();
-        if (lane == 0) w.tile_cnt[lp.tile] += total;
     }
 }
 
@@ -543,33 +655,49 @@ __global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
     if (tid == 0) {
         w.tile_off[w.n_tiles] = (int64_t)s_base;
         w.result->n_tokens = (int64_t)s_base;
-        w.result->n_long = *w.long_count;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pack: tiles' tokens -> one packed stream; per-document token offsets
+// pack: tok_at -> one packed token stream in position (= document) order; token-start masks and
+// per-block counts for the per-document offsets
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_pack_tokens(JtkWork w) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_id[T];
+    __shared__ uint64_t s_tm[TW];
+    __shared__ uint32_t s_cnt[TW];
+    __shared__ uint32_t s_pre[TW + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t tile = blockIdx.x;
-    const uint32_t cnt = w.tile_cnt[tile];
-    const int32_t* src = w.tmp_tok + w.tile_fs[tile];
+    const int64_t B = tile * T;
+    for (int i = tid; i < T / 4; i += 256)
+        reinterpret_cast<uint4*>(s_id)[i] = reinterpret_cast<const uint4*>(w.tok_at + B)[i];
+    __syncthreads();
+    for (int blk = wv; blk < TW; blk += 4) {
+        const uint64_t bal = __ballot(s_id[blk * 64 + lane] != JTK_ID_DEAD);
+        if (lane == 0) { s_tm[blk] = bal; s_cnt[blk] = (uint32_t)__popcll(bal); }
+    }
+    __syncthreads();
+    if (wv == 0) wave_scan_small(s_cnt, s_pre, TW);
+    __syncthreads();
     int32_t* dst = w.tokens + w.tile_off[tile];
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
+    for (int blk = wv; blk < TW; blk += 4) {
+        const uint64_t m = s_tm[blk];
+        if ((m >> lane) & 1ull) dst[s_pre[blk] + __popcll(m & lanemask_lt())] = (int32_t)s_id[blk * 64 + lane];
+    }
+    if (tid < TW) {
+        const int64_t wd = (B >> 6) + tid;
+        if (wd < w.n_words) { w.tokmask[wd] = s_tm[tid]; w.blk_pre[wd] = (uint16_t)s_pre[tid]; }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_doc_offsets(JtkWork w) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > w.n_docs) return;
     const int64_t q = w.doc_off[d];
-    const int64_t tile = q / MT;
-    const int64_t fs = w.tile_fs[tile];
     const int64_t wd = q >> 6;
-    uint64_t m = w.tokmask[wd] & ((1ull << (q & 63)) - 1ull);
-    uint32_t pre = 0;
-    if ((fs >> 6) == wd) m &= ~((1ull << (fs & 63)) - 1ull);       // bits before fs belong to the previous tile
-    else pre = w.blk_pre[wd];
-    w.tok_off[d] = w.tile_off[tile] + pre + __popcll(m);
+    const uint64_t m = w.tokmask[wd] & ((1ull << (q & 63)) - 1ull);
+    w.tok_off[d] = w.tile_off[q / T] + w.blk_pre[wd] + __popcll(m);
     if (d < w.n_docs) {
         const int32_t st = w.status[d];
         if (st < 0) atomicMin(&w.result->worst_status, st);
@@ -592,11 +720,17 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
     if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
     else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
 }
+void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
+    hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
+}
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    hipLaunchKernelGGL(k_bpe_merge, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
+    const unsigned groups = (unsigned)((w.n_tiles + JTK_HARD_GROUP - 1) / JTK_HARD_GROUP);
+    hipLaunchKernelGGL((k_bpe_merge<16, 256>), dim3(groups), dim3(256), 0, s, w, t);
+    hipLaunchKernelGGL((k_bpe_merge<64, 64>), dim3(groups), dim3(64), 0, s, w, t);
 }
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    hipLaunchKernelGGL(k_bpe_merge_long, dim3(256), dim3(64), 0, s, w, t);
+    hipLaunchKernelGGL(k_bpe_merge_long<JTK_MID_CAP>, dim3(2048), dim3(64), 0, s, w, t);
+    hipLaunchKernelGGL(k_bpe_merge_long<JTK_LONG_CAP>, dim3(256), dim3(64), 0, s, w, t);
 }
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, w);

@@ -1,0 +1,210 @@
+// jtk_split_masks.h -- the split rules of jtk_split_rules.h evaluated for 64 bytes at a time on bit masks.
+//
+// One wave classifies a 64-byte block (one lane per byte) and turns the per-lane predicates into
+// 64-bit masks with __ballot; everything below is then scalar bit algebra on those masks (bit j =
+// byte j of the block), so the cost per block is independent of what the bytes are.  "prev"/"next"
+// byte relations are shifts with the neighbouring blocks' edge bits carried in.  The rules are the
+// ones derived in jtk_split_rules.h (same reference lines); the few positions whose answer needs an
+// unbounded walk (a non-CR/LF whitespace char right after a CR/LF that was not swallowed by an
+// O-piece; runs whose start lies before the wave's first block) are returned in `slow` and are
+// evaluated with jtk_is_piece_start_t instead.
+#ifndef JTK_SPLIT_MASKS_H
+#define JTK_SPLIT_MASKS_H
+
+#include "jtk_common.h"
+
+struct JtkBlk {                 // class masks of one 64-byte block
+    uint64_t L, N, W;           // class of the character each byte belongs to (O = none of them)
+    uint64_t CONT, NL, SP, DS, AP;
+    uint64_t S1, RV, E, LL, C5, BF;   // contraction letters: s|t|m|d, r|v, e, l, 0xC5, 0xBF (case folded for cl100k)
+};
+
+struct JtkSplitCarry {          // state handed from block b to block b+1
+    uint64_t pL, pN, pW, pNL, pSP, pDS, pCONT;  // the previous block's masks (only the top 3 bits are used)
+    uint64_t pS1, pRV, pE, pLL, pC5, pBF;
+    uint64_t pMsAP;             // apostrophes of the previous block that start a match
+    uint64_t pX;                // bytes of O characters that start a match (previous block)
+    uint64_t pSW;               // CR/LF bytes swallowed by an O piece (previous block)
+    uint32_t ncnt;              // N characters in the digit run that ends at the previous block's last byte, mod 3
+    bool n_unknown;             // ... that run started before the wave's first block
+    bool sw_unknown;            // the CR/LF chain ending the previous block started before the wave's first block
+};
+
+JTK_HD int jtk_popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll((unsigned long long)x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+JTK_HD int jtk_hibit64(uint64_t x) {   // index of the highest set bit, x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 63 - __clzll((long long)x);
+#else
+    return 63 - __builtin_clzll(x);
+#endif
+}
+
+// bits of `seed` extended upwards through consecutive set bits of `through`
+JTK_HD uint64_t jtk_fill_up(uint64_t seed, uint64_t through) {
+    uint64_t x = seed, m = through;
+    x |= (x << 1) & m;  m &= m << 1;
+    x |= (x << 2) & m;  m &= m << 2;
+    x |= (x << 4) & m;  m &= m << 4;
+    x |= (x << 8) & m;  m &= m << 8;
+    x |= (x << 16) & m; m &= m << 16;
+    x |= (x << 32) & m;
+    return x;
+}
+
+JTK_HD void jtk_split_carry_init(JtkSplitCarry& c) {
+    c.pL = c.pN = c.pW = c.pNL = c.pSP = c.pDS = c.pCONT = 0;
+    c.pS1 = c.pRV = c.pE = c.pLL = c.pC5 = c.pBF = 0;
+    c.pMsAP = c.pX = c.pSW = 0;
+    c.ncnt = 0;
+    c.n_unknown = false;
+    c.sw_unknown = false;
+}
+
+// cl100k: is the N character whose lead byte is bit j of the block (not a document start) a piece
+// start?  "\p{N}{1,3}": every third character of the digit run.  `slow` is set when the run started
+// before the wave's first block.
+JTK_HD bool jtk_split_n_lane(const JtkBlk& cu, uint32_t ncnt, bool n_unknown, int j, bool& slow) {
+    const uint64_t below = (1ull << j) - 1ull;
+    const uint64_t lead = ~cu.CONT;
+    const uint64_t Z = (~cu.N | cu.DS) & below;          // run breakers below j
+    uint32_t cnt;
+    if (Z == 0) {
+        if (n_unknown) { slow = true; return false; }
+        cnt = (uint32_t)jtk_popc64(lead & below) + ncnt;
+    } else {
+        const int hb = jtk_hibit64(Z);
+        const int start = ((cu.N >> hb) & (cu.DS >> hb) & 1ull) ? hb : hb + 1;
+        cnt = (uint32_t)jtk_popc64(cu.N & lead & below & ~((1ull << start) - 1ull));
+    }
+    return cnt % 3u == 0u;
+}
+
+// Piece-start mask of block `cu` for the positions that are decided by mask algebra; `slow` gets the
+// positions the caller must evaluate per lane (for cl100k it always contains the N lead bytes that
+// are not document starts: they go through jtk_split_n_lane).  `nx` supplies the next block (only
+// its low 4 bits are used).  Updates `cy` for the next block.
+template <int KIND>
+JTK_HD uint64_t jtk_split_block(const JtkBlk& cu, const JtkBlk& nx, JtkSplitCarry& cy, uint64_t& slow, uint64_t& nlanes) {
+    constexpr bool cl = (KIND == JTK_PAT_CL100K);
+#define JTK_P1(cur, prv) (((cur) << 1) | ((prv) >> 63))
+#define JTK_PK(cur, prv, k) (((cur) << (k)) | ((prv) >> (64 - (k))))
+#define JTK_N1(cur, nxt) (((cur) >> 1) | ((nxt) << 63))
+    const uint64_t lead = ~cu.CONT, notDS = ~cu.DS;
+    const uint64_t O = ~(cu.L | cu.N | cu.W);
+    const uint64_t pL = JTK_P1(cu.L, cy.pL), pN = JTK_P1(cu.N, cy.pN), pW = JTK_P1(cu.W, cy.pW);
+    const uint64_t pO = ~(pL | pN | pW);
+    const uint64_t pSP = JTK_P1(cu.SP, cy.pSP), pNL = JTK_P1(cu.NL, cy.pNL), pDS = JTK_P1(cu.DS, cy.pDS);
+
+    // O characters that start a match (incl. document starts), and all bytes of those characters
+    const uint64_t mso = O & lead & (cu.DS | (~pO & ~pSP));
+    uint64_t X = mso | ((cy.pX >> 63) & cu.CONT & 1ull);
+    X |= (X << 1) & cu.CONT;
+    X |= (X << 1) & cu.CONT;
+    X |= (X << 1) & cu.CONT;
+    const uint64_t prevIsMsO = JTK_P1(X, cy.pX);
+    const uint64_t msAP = cu.AP & mso;
+
+    // ---- letters
+    const uint64_t ctr2 = JTK_PK(msAP, cy.pMsAP, 2) & JTK_P1(cu.S1, cy.pS1) & ~pDS;
+    uint64_t tail3 = (JTK_PK(cu.RV, cy.pRV, 2) & JTK_P1(cu.E, cy.pE)) | (JTK_PK(cu.LL, cy.pLL, 2) & JTK_P1(cu.LL, cy.pLL));
+    if (cl) tail3 |= JTK_PK(cu.C5, cy.pC5, 2) & JTK_P1(cu.BF, cy.pBF);
+    const uint64_t ctr3 = JTK_PK(msAP, cy.pMsAP, 3) & tail3 & ~pDS & ~JTK_PK(cu.DS, cy.pDS, 2);
+    uint64_t afterO;
+    if (cl) afterO = ~prevIsMsO;
+    else {
+        // r50k: no one-char prefix; only "the letter of a contraction" is not a start
+        const uint64_t c_here = cu.S1 | (((cu.RV & JTK_N1(cu.E, nx.E)) | (cu.LL & JTK_N1(cu.LL, nx.LL))) & ~JTK_N1(cu.DS, nx.DS));
+        afterO = ~(JTK_P1(msAP, cy.pMsAP) & c_here);
+    }
+    const uint64_t afterW = cl ? pNL : ~pSP;
+    const uint64_t Lms = cu.L & lead & notDS & (pN | (pW & afterW) | (pO & afterO) | (pL & (ctr2 | ctr3)));
+
+    // ---- numbers
+    uint64_t Nms = 0;
+    nlanes = 0;
+    if (cl) nlanes = cu.N & lead & notDS;                      // per lane: jtk_split_n_lane
+    else Nms = cu.N & lead & notDS & ~pN & ~pSP;
+
+    // ---- whitespace
+    const uint64_t nW = JTK_N1(cu.W, nx.W), nDS = JTK_N1(cu.DS, nx.DS);
+    uint64_t ylo = cu.W & (~nW | nDS) & ~nDS;                  // last byte of a run that is followed by text
+    uint64_t yhi = nx.W & (~(nx.W >> 1) | (nx.DS >> 1)) & ~(nx.DS >> 1) & 7ull;
+    for (int it = 0; it < 3; it++) {                           // move the flag to the character's lead byte
+        const uint64_t lo_c = ylo & cu.CONT, hi_c = yhi & nx.CONT;
+        ylo = (ylo & lead) | (lo_c >> 1) | ((hi_c & 1ull) << 63);
+        yhi = (yhi & ~nx.CONT) | (hi_c >> 1);
+    }
+    const uint64_t wlead = cu.W & lead & notDS;
+    uint64_t Wms;
+    slow = 0;
+    uint64_t SW = 0;
+    if (!cl) {
+        Wms = wlead & (~pW | ylo);
+    } else {
+        // CR/LF directly after an O character (and the CR/LFs chained to them) belong to the O piece
+        uint64_t seed = cu.NL & pO & notDS;
+        const uint64_t chain0 = jtk_fill_up(cu.NL & notDS & 1ull, cu.NL & notDS);   // CR/LF chain from byte 0
+        if ((cy.pSW >> 63) & 1ull) seed |= cu.NL & notDS & 1ull;
+        SW = jtk_fill_up(seed, cu.NL & notDS);
+        const uint64_t pSW = JTK_P1(SW, cy.pSW);
+        const uint64_t plain = wlead & ~cu.NL & ~pNL;          // neither a CR/LF nor right after one
+        const uint64_t nl = wlead & cu.NL;
+        const uint64_t afterNL = wlead & ~cu.NL & pNL;
+        Wms = (plain & (~pW | ylo)) | (nl & ~SW & ~pW) | (afterNL & pSW);
+        slow = afterNL & ~pSW;
+        if (cy.sw_unknown) {
+            // the chain's origin is not visible: its bytes, and the char right after it, go the slow way
+            const uint64_t after0 = (chain0 << 1) & wlead & ~cu.NL;
+            slow |= (chain0 & wlead) | after0;
+        }
+        // carry: does the chain at the end of this block still have an invisible origin?
+        const bool whole = chain0 == ~0ull;
+        cy.sw_unknown = cy.sw_unknown && whole;
+    }
+
+    const uint64_t ms = cu.DS | mso | Lms | Nms | Wms;
+
+    // ---- carry for the next block
+    if (cl) {
+        if (!((cu.N >> 63) & 1ull)) { cy.ncnt = 0; cy.n_unknown = false; }
+        else {
+            const uint64_t Z = (~cu.N | cu.DS);
+            if (Z == 0) cy.ncnt = (cy.ncnt + (uint32_t)jtk_popc64(lead)) % 3u;   // n_unknown unchanged
+            else {
+                const int hb = jtk_hibit64(Z);
+                const int start = ((cu.N >> hb) & (cu.DS >> hb) & 1ull) ? hb : hb + 1;
+                cy.ncnt = (start > 63) ? 0u : (uint32_t)jtk_popc64(cu.N & lead & ~((1ull << start) - 1ull)) % 3u;
+                cy.n_unknown = false;
+            }
+        }
+    }
+    cy.pL = cu.L; cy.pN = cu.N; cy.pW = cu.W; cy.pNL = cu.NL; cy.pSP = cu.SP; cy.pDS = cu.DS; cy.pCONT = cu.CONT;
+    cy.pS1 = cu.S1; cy.pRV = cu.RV; cy.pE = cu.E; cy.pLL = cu.LL; cy.pC5 = cu.C5; cy.pBF = cu.BF;
+    cy.pMsAP = msAP; cy.pX = X; cy.pSW = SW;
+#undef JTK_P1
+#undef JTK_PK
+#undef JTK_N1
+    return ms;
+}
+
+// Carry for a wave that starts at block `first`: derived from the block before it alone.  Runs or
+// CR/LF chains that cover that whole block have an origin the wave cannot see (flags *_unknown).
+template <int KIND>
+JTK_HD void jtk_split_carry_from_halo(const JtkBlk& halo, const JtkBlk& first, JtkSplitCarry& cy) {
+    jtk_split_carry_init(cy);
+    uint64_t slow, nl;
+    (void)jtk_split_block<KIND>(halo, first, cy, slow, nl);
+    if (KIND == JTK_PAT_CL100K) {
+        cy.n_unknown = ((~halo.N | halo.DS) == 0);
+        const uint64_t nlm = halo.NL & ~halo.DS;
+        cy.sw_unknown = (nlm == ~0ull);
+    }
+}
+
+#endif

@@ -8,6 +8,7 @@
 
 #include "../../jtokkit_amd/csrc/jtk_common.h"
 #include "../../jtokkit_amd/csrc/jtk_split_rules.h"
+#include "../../jtokkit_amd/csrc/jtk_split_masks.h"
 #include "../../jtokkit_amd/csrc/jtk_unicode_tables.h"
 
 namespace {
@@ -38,6 +39,82 @@ int sim_split(int kind, const uint8_t* text, int64_t n, const int64_t* doc_off, 
     return 0;
 }
 
+}  // extern "C"
+
+// The kernel's form: 64-byte blocks as bit masks (jtk_split_masks.h), waves of `wave_blocks` blocks that
+// each start from the block before them, slow lanes through jtk_is_piece_start_t.
+static JtkBlk make_blk(const uint8_t* text, int64_t n, const uint8_t* cb, int64_t b, bool ci) {
+    JtkBlk k;
+    memset(&k, 0, sizeof(k));
+    for (int j = 0; j < 64; j++) {
+        const int64_t p = b * 64 + j;
+        const uint64_t bit = 1ull << j;
+        if (p < 0) continue;
+        if (p >= n) { k.DS |= bit; continue; }
+        const uint32_t c = cb[p], raw = text[p];
+        const uint32_t cls = c & JTK_CB_CLS;
+        if (cls == JTK_CLS_L) k.L |= bit;
+        if (cls == JTK_CLS_N) k.N |= bit;
+        if (cls == JTK_CLS_W) k.W |= bit;
+        if (c & JTK_CB_CONT) k.CONT |= bit;
+        if (c & JTK_CB_NL) k.NL |= bit;
+        if (c & JTK_CB_SP) k.SP |= bit;
+        if (c & JTK_CB_DS) k.DS |= bit;
+        if (raw == '\'') k.AP |= bit;
+        const uint32_t f = (ci && (raw - 'A') < 26u) ? (raw | 0x20u) : raw;
+        if (f == 's' || f == 't' || f == 'm' || f == 'd') k.S1 |= bit;
+        if (f == 'r' || f == 'v') k.RV |= bit;
+        if (f == 'e') k.E |= bit;
+        if (f == 'l') k.LL |= bit;
+        if (raw == 0xC5) k.C5 |= bit;
+        if (raw == 0xBF) k.BF |= bit;
+    }
+    return k;
+}
+
+template <int KIND>
+static void sim_split_masks_t(const uint8_t* text, int64_t n, const uint8_t* cbv, int wave_blocks, uint8_t* ms_out,
+                              int64_t* n_slow) {
+    Win w{text, n, cbv};
+    const bool ci = KIND == JTK_PAT_CL100K;
+    const int64_t nblk = (n + 1 + 63) / 64;
+    for (int64_t f = 0; f < nblk; f += wave_blocks) {
+        JtkSplitCarry cy;
+        JtkBlk halo = make_blk(text, n, cbv, f - 1, ci), cu = make_blk(text, n, cbv, f, ci);
+        jtk_split_carry_from_halo<KIND>(halo, cu, cy);
+        for (int64_t b = f; b < f + wave_blocks && b < nblk; b++) {
+            JtkBlk nx = make_blk(text, n, cbv, b + 1, ci);
+            uint64_t slow = 0, nl = 0;
+            const JtkSplitCarry before = cy;
+            uint64_t ms = jtk_split_block<KIND>(cu, nx, cy, slow, nl);
+            for (int j = 0; j < 64; j++) {
+                const int64_t p = b * 64 + j;
+                if (p > n) break;
+                bool v = (ms >> j) & 1ull;
+                bool sl = (slow >> j) & 1ull;
+                if ((nl >> j) & 1ull) { bool s2 = false; v = jtk_split_n_lane(cu, before.ncnt, before.n_unknown, j, s2); sl = sl || s2; }
+                if (sl) { bool dummy = false; v = jtk_is_piece_start_t<KIND>(w, p, dummy); (*n_slow)++; }
+                ms_out[p] = v ? 1 : 0;
+            }
+            cu = nx;
+        }
+    }
+}
+
+extern "C" int sim_split_masks(int kind, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs,
+                               int wave_blocks, uint8_t* ms_out, int64_t* n_slow) {
+    JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};
+    std::vector<uint8_t> cb((size_t)n + 1);
+    Txt txt{text, n};
+    for (int64_t p = 0; p < n; p++) cb[p] = (uint8_t)jtk_class_byte(txt, u, p);
+    for (int64_t d = 0; d <= n_docs; d++) if (doc_off[d] < n) cb[doc_off[d]] |= JTK_CB_DS;
+    *n_slow = 0;
+    if (kind == JTK_PAT_CL100K) sim_split_masks_t<JTK_PAT_CL100K>(text, n, cb.data(), wave_blocks, ms_out, n_slow);
+    else sim_split_masks_t<JTK_PAT_R50K>(text, n, cb.data(), wave_blocks, ms_out, n_slow);
+    return 0;
+}
+
+extern "C" {
 uint32_t sim_class_byte(const uint8_t* text, int64_t n, int64_t p) {
     JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};
     Txt txt{text, n};
