@@ -202,70 +202,136 @@ __device__ __forceinline__ JtkBlk classify_block(const uint8_t* s_tx, const uint
     return k;
 }
 
+// Two phases per wave.  (1) Byte-parallel: for each of 64 consecutive blocks the wave classifies one
+// byte per lane and the ballot masks are deposited in the registers of lane l (one select per dword), so that
+// afterwards LANE l OWNS BLOCK l.  (2) Block-parallel: every lane runs the mask algebra of
+// jtk_split_masks.h for its own block with 64-bit VALU ops; the block-to-block carries (swallowed
+// CR/LF chains, digit-run phase, ...) are exchanged with __shfl_up and iterated to a fixed point
+// (one or two rounds unless a run spans several blocks).  Lanes 0 and 63 are halo blocks: a wave
+// emits 62 mask words, a workgroup 248 (15,872 bytes of text).
+constexpr int SPW = 62;                                // blocks a wave emits
+constexpr int SPLIT_BYTES = 4 * SPW * 64;              // bytes per workgroup
+constexpr int S_WIN2 = SPLIT_BYTES + 2 * 64;           // window [B-64, B+SPLIT_BYTES+64)
+constexpr int S_TX2 = S_WIN2 + 8;
+
+__device__ __forceinline__ uint64_t writelane64(uint64_t v, int l, uint64_t old) {
+    return ((int)(threadIdx.x & 63u) == l) ? v : old;          // v is wave-uniform: a select per dword
+}
+__device__ __forceinline__ uint64_t hi_from_prev_lane(uint64_t v) {      // only the top bits are consumed
+    return (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1) << 32;
+}
+__device__ __forceinline__ uint64_t lo_from_next_lane(uint64_t v) {      // only the low bits are consumed
+    return (uint64_t)(uint32_t)__shfl_down((int)(uint32_t)v, 1);
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables t) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tx[S_TX];
-    __shared__ uint64_t s_dm[S_WIN / 64 + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tx[S_TX2];
+    __shared__ uint64_t s_dm[S_WIN2 / 64 + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t B = (int64_t)blockIdx.x * ST;
-    const int64_t lo = B - SH, tlo = lo - 4;
+    const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
+    const int64_t lo = B - 64, tlo = lo - 4;
     const int64_t n = w.n_bytes;
 
-    // text window, 4 bytes per lane per step (tlo is 4-byte aligned)
-    for (int i = tid; i < S_TX / 4; i += 256) {
+    for (int i = tid; i < S_TX2 / 4; i += 256) {
         const int64_t p = tlo + (int64_t)i * 4;
         uint32_t v = 0;
         if (p >= 0 && p + 4 <= n) v = *reinterpret_cast<const uint32_t*>(w.text + p);
         else for (int j = 0; j < 4; j++) { const int64_t q = p + j; if (q >= 0 && q < n) v |= (uint32_t)w.text[q] << (8 * j); }
         reinterpret_cast<uint32_t*>(s_tx)[i] = v;
     }
-    if (tid < S_WIN / 64 + 1) {
-        const int64_t wd = (lo >> 6) + tid;
-        s_dm[tid] = (wd >= 0 && wd < w.n_words) ? w.docmask[wd] : 0ull;
+    for (int i = tid; i < S_WIN2 / 64 + 1; i += 256) {
+        const int64_t wd = (lo >> 6) + i;
+        s_dm[i] = (wd >= 0 && wd < w.n_words) ? w.docmask[wd] : 0ull;
     }
     __syncthreads();
 
-    constexpr int BPW = ST / 64 / 4;                                  // blocks per wave
-    const int wb0 = 1 + wv * BPW;                                     // window block of the wave's first block
-    JtkBlk cu = classify_block<KIND>(s_tx, s_dm, wb0, lo, n, t.uc);
-    JtkSplitCarry cy;
-    {
-        const JtkBlk halo = classify_block<KIND>(s_tx, s_dm, wb0 - 1, lo, n, t.uc);
-        jtk_split_carry_from_halo<KIND>(halo, cu, cy);
+    // ---- phase 1: lane l gets the masks of window block wv*SPW + l
+    const int wb0 = wv * SPW;
+    JtkBlk cu;
+    cu.L = cu.N = cu.W = cu.CONT = cu.NL = cu.SP = cu.DS = cu.AP = 0;
+    cu.S1 = cu.RV = cu.E = cu.LL = cu.C5 = cu.BF = 0;
+    for (int l = 0; l < 64; l++) {
+        const JtkBlk k = classify_block<KIND>(s_tx, s_dm, wb0 + l, lo, n, t.uc);
+        cu.L = writelane64(k.L, l, cu.L);       cu.N = writelane64(k.N, l, cu.N);
+        cu.W = writelane64(k.W, l, cu.W);       cu.CONT = writelane64(k.CONT, l, cu.CONT);
+        cu.NL = writelane64(k.NL, l, cu.NL);    cu.SP = writelane64(k.SP, l, cu.SP);
+        cu.DS = writelane64(k.DS, l, cu.DS);    cu.AP = writelane64(k.AP, l, cu.AP);
+        cu.S1 = writelane64(k.S1, l, cu.S1);    cu.RV = writelane64(k.RV, l, cu.RV);
+        cu.E = writelane64(k.E, l, cu.E);       cu.LL = writelane64(k.LL, l, cu.LL);
+        cu.C5 = writelane64(k.C5, l, cu.C5);    cu.BF = writelane64(k.BF, l, cu.BF);
     }
-    for (int b = 0; b < BPW; b++) {
-        const int wb = wb0 + b;
-        const JtkBlk nx = classify_block<KIND>(s_tx, s_dm, wb + 1, lo, n, t.uc);
-        const uint32_t ncnt0 = cy.ncnt;
-        const bool nunk0 = cy.n_unknown;
-        uint64_t slow, nlanes;
-        const uint64_t ms = jtk_split_block<KIND>(cu, nx, cy, slow, nlanes);
-        bool v = (ms >> lane) & 1ull;
-        bool sl = (slow >> lane) & 1ull;
-        if (nlanes) {                                                 // cl100k digit runs: every third char
-            if ((nlanes >> lane) & 1ull) { bool s2 = false; v = jtk_split_n_lane(cu, ncnt0, nunk0, lane, s2); sl = sl || s2; }
+
+    // ---- phase 2: lane = block
+    JtkBlk nx;
+    nx.L = nx.N = nx.NL = nx.SP = nx.AP = nx.S1 = nx.RV = nx.C5 = nx.BF = 0;
+    nx.W = lo_from_next_lane(cu.W); nx.DS = lo_from_next_lane(cu.DS); nx.CONT = lo_from_next_lane(cu.CONT);
+    nx.E = lo_from_next_lane(cu.E); nx.LL = lo_from_next_lane(cu.LL);
+    JtkSplitCarry base;
+    base.pL = hi_from_prev_lane(cu.L);   base.pN = hi_from_prev_lane(cu.N);   base.pW = hi_from_prev_lane(cu.W);
+    base.pNL = hi_from_prev_lane(cu.NL); base.pSP = hi_from_prev_lane(cu.SP); base.pDS = hi_from_prev_lane(cu.DS);
+    base.pCONT = hi_from_prev_lane(cu.CONT);
+    base.pS1 = hi_from_prev_lane(cu.S1); base.pRV = hi_from_prev_lane(cu.RV); base.pE = hi_from_prev_lane(cu.E);
+    base.pLL = hi_from_prev_lane(cu.LL); base.pC5 = hi_from_prev_lane(cu.C5); base.pBF = hi_from_prev_lane(cu.BF);
+
+    uint64_t oX = 0, oAP = 0, oSW = 0;            // what this lane hands to the next one
+    uint32_t oN = 0, oFlags = 0;                  // bit0 n_unknown, bit1 sw_unknown
+    uint64_t ms = 0, slow = 0, nlanes = 0;
+    uint32_t ncnt_in = 0;
+    bool nunk_in = false;
+    for (int round = 0; round < 66; round++) {
+        JtkSplitCarry cy = base;
+        cy.pX = hi_from_prev_lane(oX);
+        cy.pMsAP = hi_from_prev_lane(oAP);
+        cy.pSW = hi_from_prev_lane(oSW);
+        cy.ncnt = (uint32_t)__shfl_up((int)oN, 1);
+        const uint32_t fl = (uint32_t)__shfl_up((int)oFlags, 1);
+        cy.n_unknown = (fl & 1u) != 0;
+        cy.sw_unknown = (fl & 2u) != 0;
+        if (lane == 0) { cy.pX = cy.pMsAP = cy.pSW = 0; cy.ncnt = 0; cy.n_unknown = true; cy.sw_unknown = true; }
+        ncnt_in = cy.ncnt;
+        nunk_in = cy.n_unknown;
+        ms = jtk_split_block<KIND>(cu, nx, cy, slow, nlanes);
+        const uint32_t nfl = (cy.n_unknown ? 1u : 0u) | (cy.sw_unknown ? 2u : 0u);
+        const bool changed = ((cy.pX ^ oX) >> 61) != 0 || ((cy.pMsAP ^ oAP) >> 61) != 0 || ((cy.pSW ^ oSW) >> 63) != 0
+                             || cy.ncnt != oN || nfl != oFlags;
+        oX = cy.pX; oAP = cy.pMsAP; oSW = cy.pSW; oN = cy.ncnt; oFlags = nfl;
+        if (!__ballot(changed)) break;
+    }
+
+    // ---- per-position work that is not mask algebra: cl100k digit runs, and the rare slow positions
+    const int wb = wb0 + lane;
+    for (uint64_t m = nlanes; m;) {
+        const int j = jtk_ctz64(m);
+        m &= m - 1;
+        bool s2 = false;
+        const bool v = jtk_split_n_lane(cu, ncnt_in, nunk_in, j, s2);
+        if (s2) slow |= 1ull << j;
+        else if (v) ms |= 1ull << j;
+    }
+    for (uint64_t m = slow; m;) {
+        const int j = jtk_ctz64(m);
+        m &= m - 1;
+        const int i = wb * 64 + j;
+        const FastWin fw{s_tx, s_dm, lo, n, t.uc};
+        bool unresolved = false;
+        bool v = jtk_is_piece_start_t<KIND>(fw, i, unresolved);
+        if (unresolved) {
+            const SlowWin sw{w.text, n, w.docmask, t.uc};
+            bool dummy = false;
+            v = jtk_is_piece_start_t<KIND>(sw, lo + i, dummy);
         }
-        const int i = wb * 64 + lane;
-        const int64_t p = lo + i;
-        if (__ballot(sl)) {
-            if (sl) {
-                const FastWin fw{s_tx, s_dm, lo, n, t.uc};
-                bool unresolved = false;
-                v = jtk_is_piece_start_t<KIND>(fw, i, unresolved);
-                if (unresolved) {
-                    const SlowWin sw{w.text, n, w.docmask, t.uc};
-                    bool dummy = false;
-                    v = jtk_is_piece_start_t<KIND>(sw, p, dummy);
-                }
-            }
-        }
-        const uint64_t bal = __ballot(v && p <= n);
-        if (lane == 0) {
-            const int64_t wd = p >> 6;
-            if (wd < w.n_words) w.piecemask[wd] = bal;
-        }
-        cu = nx;
+        ms = v ? (ms | (1ull << j)) : (ms & ~(1ull << j));
+    }
+
+    if (lane >= 1 && lane <= SPW) {
+        const int64_t p0 = lo + (int64_t)wb * 64;
+        uint64_t valid = 0;                                           // positions <= n
+        if (p0 + 63 <= n) valid = ~0ull;
+        else if (p0 <= n) valid = (2ull << (n - p0)) - 1ull;
+        const int64_t wd = p0 >> 6;
+        if (wd < w.n_words) w.piecemask[wd] = ms & valid;
     }
 }
 
@@ -449,8 +515,9 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     __shared__ uint32_t s_rk[SLOTS * THREADS];
     __shared__ uint32_t s_brank[256];
     __shared__ uint32_t s_tc[JTK_HARD_GROUP + 1];
+    __shared__ uint32_t s_next;
     constexpr int G = JTK_HARD_GROUP;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t g0 = (int64_t)blockIdx.x * G;
     const uint32_t* list = (SLOTS == 16) ? w.hard16 : w.hard64;
     const uint32_t* cnts = (SLOTS == 16) ? w.n_hard16 : w.n_hard64;
@@ -464,43 +531,65 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     if (total == 0) return;
     for (int i = tid; i < 256; i += THREADS) s_brank[i] = t.byte_rank[i];
     if (tid <= G) s_tc[tid] = 0;
+    if (tid == 0) s_next = 0;
     __syncthreads();
 
     uint32_t* const ids = s_ids + tid;
     uint32_t* const rk = s_rk + tid;
     const JtkPairTable pt = t.pairs;
-    for (uint32_t i = tid; i < total; i += THREADS) {
-        int g = 0;
-        uint32_t gbase = 0;
+
+    // Every lane is a small state machine: take the next queued piece, set up its parts, then one merge
+    // per loop trip until no pair is left; lanes re-arm independently, so the wave stays full while the
+    // queue lasts and many lookup chains are in flight.
+    bool active = false, exhausted = false;
+    int64_t pos = 0;
+    int g = 0;
+    uint64_t alive = 0;
+    for (;;) {
+        const uint64_t want = __ballot(!active && !exhausted);
+        if (want) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, (uint32_t)__popcll(want));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (!active && !exhausted) {
+                const uint32_t i = base + (uint32_t)__popcll(want & lanemask_lt());
+                if (i >= total) exhausted = true;
+                else {
+                    g = 0;
+                    uint32_t gbase = 0;
 #pragma unroll
-        for (int q = 1; q < G; q++) if (i >= pre[q]) { g = q; gbase = pre[q]; }
-        const uint32_t entry = list[(g0 + g) * CAP + (i - gbase)];
-        const int64_t pos = (g0 + g) * T + (entry & 4095u);
-        const int len = (int)(entry >> 12);
-        // stage the piece's bytes (aligned dwords) in the rk slots, then expand to ids / pair ranks
-        const uint32_t off = (uint32_t)(pos & 3);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(w.text + (pos - off));
-        constexpr int NDW = SLOTS / 4 + 1;
+                    for (int q = 1; q < G; q++) if (i >= pre[q]) { g = q; gbase = pre[q]; }
+                    const uint32_t entry = list[(g0 + g) * CAP + (i - gbase)];
+                    pos = (g0 + g) * T + (entry & 4095u);
+                    const int len = (int)(entry >> 12);
+                    // stage the piece's bytes (aligned dwords) in the rk slots, then expand to ids / pair ranks
+                    const uint32_t off = (uint32_t)(pos & 3);
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(w.text + (pos - off));
+                    constexpr int NDW = SLOTS / 4 + 1;
 #pragma unroll
-        for (int k = 0; k < NDW; k++)
-            if ((int)(k * 4) < (int)off + len) rk[k * THREADS] = src[k];
-        const uint8_t* rkb = reinterpret_cast<const uint8_t*>(rk);
-        uint32_t prev = rkb[(off >> 2) * THREADS * 4 + (off & 3)];
-        for (int j = 0; j + 1 < len; j++) {
-            const uint32_t o = off + j + 1;
-            const uint32_t cur = rkb[(o >> 2) * THREADS * 4 + (o & 3)];
-            ids[j * THREADS] = (prev << 8) | cur;                       // byte pair, expanded below
-            prev = cur;
+                    for (int k = 0; k < NDW; k++)
+                        if ((int)(k * 4) < (int)off + len) rk[k * THREADS] = src[k];
+                    const uint8_t* rkb = reinterpret_cast<const uint8_t*>(rk);
+                    uint32_t prev = rkb[(off >> 2) * THREADS * 4 + (off & 3)];
+                    for (int j = 0; j + 1 < len; j++) {
+                        const uint32_t o = off + j + 1;
+                        const uint32_t cur = rkb[(o >> 2) * THREADS * 4 + (o & 3)];
+                        ids[j * THREADS] = (prev << 8) | cur;           // byte pair, expanded below
+                        prev = cur;
+                    }
+                    ids[(len - 1) * THREADS] = prev << 8;
+                    for (int j = 0; j < len; j++) {
+                        const uint32_t bp = ids[j * THREADS];
+                        rk[j * THREADS] = (j + 1 < len) ? t.bp_rank[bp] : JTK_RANK_NONE;   // :216-221
+                        ids[j * THREADS] = s_brank[bp >> 8];
+                    }
+                    alive = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);
+                    active = true;
+                }
+            }
         }
-        ids[(len - 1) * THREADS] = prev << 8;
-        for (int j = 0; j < len; j++) {
-            const uint32_t bp = ids[j * THREADS];
-            rk[j * THREADS] = (j + 1 < len) ? t.bp_rank[bp] : JTK_RANK_NONE;   // :216-221, ranks of 2-byte tokens
-            ids[j * THREADS] = s_brank[bp >> 8];
-        }
-        uint64_t alive = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);
-        int ntok = len;
-        while (ntok > 1) {                                                                   // :223
+        if (!__ballot(active)) break;
+        if (active) {
             uint32_t minr = JTK_RANK_NONE;
             int mini = 0;
             for (uint64_t m = alive; m;) {                                                   // :234-240
@@ -509,33 +598,35 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
                 const uint32_t r = rk[j * THREADS];
                 if (r < minr) { minr = r; mini = j; }
             }
-            if (minr == JTK_RANK_NONE) break;                                                // :247,:261
-            const uint64_t above = alive & ~((2ull << mini) - 1ull);
-            const int nxt = jtk_ctz64(above);
-            const uint64_t above2 = above & (above - 1);
-            const uint64_t below = alive & ((1ull << mini) - 1ull);
-            const int nn = above2 ? jtk_ctz64(above2) : 0;
-            const int pv = below ? 63 - jtk_clz64(below) : 0;
-            uint32_t r1, r2;
-            jtk_pair_lookup2(pt, minr, above2 ? ids[nn * THREADS] : 0u, above2 != 0, below ? ids[pv * THREADS] : 0u, minr,
-                             below != 0, r1, r2);                                            // :254-257
-            if (below) rk[pv * THREADS] = r2;
-            ids[mini * THREADS] = minr;
-            rk[mini * THREADS] = r1;
-            alive &= ~(1ull << nxt);                                                         // :259
-            ntok--;
+            if (minr != JTK_RANK_NONE) {                                                     // :247
+                const uint64_t above = alive & ~((2ull << mini) - 1ull);
+                const int nxt = jtk_ctz64(above);
+                const uint64_t above2 = above & (above - 1);
+                const uint64_t below = alive & ((1ull << mini) - 1ull);
+                const int nn = above2 ? jtk_ctz64(above2) : 0;
+                const int pv = below ? 63 - jtk_clz64(below) : 0;
+                uint32_t r1, r2;
+                jtk_pair_lookup2(pt, minr, above2 ? ids[nn * THREADS] : 0u, above2 != 0, below ? ids[pv * THREADS] : 0u,
+                                 minr, below != 0, r1, r2);                                  // :254-257
+                if (below) rk[pv * THREADS] = r2;
+                ids[mini * THREADS] = minr;
+                rk[mini * THREADS] = r1;
+                alive &= ~(1ull << nxt);                                                     // :259
+            } else {                                                                         // :261
+                // tokens go to the byte positions their parts start at; count them per tile
+                const int64_t tile_end = (g0 + g + 1) * (int64_t)T;
+                uint32_t c0 = 0, c1 = 0;
+                for (uint64_t m = alive; m;) {
+                    const int j = jtk_ctz64(m);
+                    m &= m - 1;
+                    w.tok_at[pos + j] = ids[j * THREADS];
+                    if (pos + j < tile_end) c0++; else c1++;
+                }
+                atomicAdd(&s_tc[g], c0);
+                if (c1) atomicAdd(&s_tc[g + 1], c1);
+                active = false;
+            }
         }
-        // tokens go to the byte positions their parts start at; count them per tile
-        const int64_t tile_end = (g0 + g + 1) * (int64_t)T;
-        uint32_t c0 = 0, c1 = 0;
-        for (uint64_t m = alive; m;) {
-            const int j = jtk_ctz64(m);
-            m &= m - 1;
-            w.tok_at[pos + j] = ids[j * THREADS];
-            if (pos + j < tile_end) c0++; else c1++;
-        }
-        atomicAdd(&s_tc[g], c0);
-        if (c1) atomicAdd(&s_tc[g + 1], c1);
     }
     __syncthreads();
     if (tid <= G && s_tc[tid] && g0 + tid < w.n_tiles) atomicAdd(&w.tile_cnt[g0 + tid], s_tc[tid]);
@@ -716,7 +807,7 @@ void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStr
     hipLaunchKernelGGL(k_special_check, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w, t);
 }
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    const int64_t tiles = (w.n_bytes + 1 + ST - 1) / ST;
+    const int64_t tiles = (w.n_bytes + 1 + SPLIT_BYTES - 1) / SPLIT_BYTES;
     if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
     else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
 }
