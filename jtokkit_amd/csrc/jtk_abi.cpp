@@ -121,12 +121,12 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(JTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     ENC_TRY(hipSetDevice(device));
     if (enc->uc1.ensure(sizeof(jtk_uc_stage1_init)) || enc->uc2.ensure(sizeof(jtk_uc_stage2_init)) ||
-        enc->brank.ensure(256 * 4) || enc->pairs.ensure(enc->host.pair_slots.size() * 8) ||
+        enc->brank.ensure(256 * 4) || enc->pairs.ensure(enc->host.pair_buckets.size() * sizeof(JtkPairBucket)) ||
         enc->tok8.ensure(enc->host.tok8.size() * sizeof(JtkTok8Slot)) || enc->bprank.ensure(65536 * 4)) { cleanup(); return JTK_ERR_OUT_OF_MEMORY; }
     ENC_TRY(hipMemcpy(enc->uc1.p, jtk_uc_stage1_init, sizeof(jtk_uc_stage1_init), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->uc2.p, jtk_uc_stage2_init, sizeof(jtk_uc_stage2_init), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->brank.p, enc->host.byte_rank, 256 * 4, hipMemcpyHostToDevice));
-    ENC_TRY(hipMemcpy(enc->pairs.p, enc->host.pair_slots.data(), enc->host.pair_slots.size() * 8, hipMemcpyHostToDevice));
+    ENC_TRY(hipMemcpy(enc->pairs.p, enc->host.pair_buckets.data(), enc->host.pair_buckets.size() * sizeof(JtkPairBucket), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->tok8.p, enc->host.tok8.data(), enc->host.tok8.size() * sizeof(JtkTok8Slot), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bprank.p, enc->host.bp_rank.data(), 65536 * 4, hipMemcpyHostToDevice));
 #undef ENC_TRY
@@ -135,7 +135,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     dt.uc.stage1 = (const uint8_t*)enc->uc1.p;
     dt.uc.stage2 = (const uint32_t*)enc->uc2.p;
     dt.byte_rank = (const uint32_t*)enc->brank.p;
-    dt.pairs.slots = (const uint64_t*)enc->pairs.p;
+    dt.pairs.buckets = (const JtkPairBucket*)enc->pairs.p;
     dt.pairs.bits = enc->host.pair_bits;
     dt.tok8.slots = (const JtkTok8Slot*)enc->tok8.p;
     dt.tok8.bits = enc->host.tok8_bits;

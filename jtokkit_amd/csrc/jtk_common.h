@@ -43,59 +43,67 @@ enum { JTK_PAT_R50K = 0, JTK_PAT_CL100K = 1 };
 
 JTK_HD uint64_t jtk_pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << JTK_ID_BITS) | b; }
 
-// 32-bit mix of the two ids; `bits` = log2(table slots).
+// Two-choice bucketed cuckoo table: a key lives in one of two buckets of two 8-byte slots each, so a
+// lookup is exactly two independent 16-byte loads -- never a dependent probe chain.  (On the device a
+// wave advances at the pace of its slowest lane, so "usually one probe, sometimes four" costs four.)
+// `bits` = log2(#buckets).
 JTK_HD uint32_t jtk_pair_hash(uint32_t a, uint32_t b, uint32_t bits) {
     uint32_t h = a * 0x9E3779B1u + b * 0x85EBCA77u;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
     return h >> (32 - bits);
 }
+JTK_HD uint32_t jtk_pair_hash2(uint32_t a, uint32_t b, uint32_t bits) {
+    uint32_t h = a * 0xC2B2AE3Du + b * 0x27D4EB2Fu + 0x165667B1u;
+    h ^= h >> 13;
+    h *= 0x9E3779B1u;
+    h ^= h >> 16;
+    return h >> (32 - bits);
+}
 
-struct JtkPairTable {
-    const uint64_t* slots;
-    uint32_t bits;   // log2(#slots)
+struct JtkPairBucket {          // 16 bytes: two slots
+    uint32_t s0lo, s0hi, s1lo, s1hi;
 };
+struct JtkPairTable {
+    const JtkPairBucket* buckets;
+    uint32_t bits;   // log2(#buckets)
+};
+
+JTK_HD uint32_t jtk_pair_match(const JtkPairBucket& v, uint64_t key) {
+    const uint64_t a = ((uint64_t)v.s0hi << 32) | v.s0lo, b = ((uint64_t)v.s1hi << 32) | v.s1lo;
+    if ((a >> 30) == key) return (uint32_t)(a & JTK_PAIR_RANK_MASK);
+    if ((b >> 30) == key) return (uint32_t)(b & JTK_PAIR_RANK_MASK);
+    return JTK_RANK_NONE;
+}
 
 JTK_HD uint32_t jtk_pair_lookup(const JtkPairTable& t, uint32_t a, uint32_t b) {
     const uint64_t key = jtk_pair_key(a, b);
-    const uint32_t mask = (1u << t.bits) - 1;
-    uint32_t h = jtk_pair_hash(a, b, t.bits);
-    for (;;) {
-        const uint64_t s = t.slots[h];
-        if ((s >> 30) == key) return (uint32_t)(s & JTK_PAIR_RANK_MASK);
-        if (s == JTK_PAIR_EMPTY) return JTK_RANK_NONE;
-        h = (h + 1) & mask;
-    }
+    const JtkPairBucket v1 = t.buckets[jtk_pair_hash(a, b, t.bits)];
+    const JtkPairBucket v2 = t.buckets[jtk_pair_hash2(a, b, t.bits)];
+    const uint32_t r1 = jtk_pair_match(v1, key), r2 = jtk_pair_match(v2, key);
+    return r1 != JTK_RANK_NONE ? r1 : r2;
 }
 
-// Both first probes are issued before either is examined, so the two loads overlap.
+// Two lookups, all four loads issued before any is examined.
 JTK_HD void jtk_pair_lookup2(const JtkPairTable& t, uint32_t a1, uint32_t b1, bool want1, uint32_t a2, uint32_t b2,
                              bool want2, uint32_t& r1, uint32_t& r2) {
-    const uint32_t mask = (1u << t.bits) - 1;
-    uint32_t h1 = jtk_pair_hash(a1, b1, t.bits), h2 = jtk_pair_hash(a2, b2, t.bits);
+    const JtkPairBucket none{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    JtkPairBucket v11 = none, v12 = none, v21 = none, v22 = none;
+    if (want1) { v11 = t.buckets[jtk_pair_hash(a1, b1, t.bits)]; v12 = t.buckets[jtk_pair_hash2(a1, b1, t.bits)]; }
+    if (want2) { v21 = t.buckets[jtk_pair_hash(a2, b2, t.bits)]; v22 = t.buckets[jtk_pair_hash2(a2, b2, t.bits)]; }
     const uint64_t k1 = jtk_pair_key(a1, b1), k2 = jtk_pair_key(a2, b2);
-    uint64_t s1 = want1 ? t.slots[h1] : JTK_PAIR_EMPTY;
-    uint64_t s2 = want2 ? t.slots[h2] : JTK_PAIR_EMPTY;
-    for (;;) {
-        if ((s1 >> 30) == k1) { r1 = (uint32_t)(s1 & JTK_PAIR_RANK_MASK); break; }
-        if (s1 == JTK_PAIR_EMPTY) { r1 = JTK_RANK_NONE; break; }
-        h1 = (h1 + 1) & mask;
-        s1 = t.slots[h1];
-    }
-    for (;;) {
-        if ((s2 >> 30) == k2) { r2 = (uint32_t)(s2 & JTK_PAIR_RANK_MASK); break; }
-        if (s2 == JTK_PAIR_EMPTY) { r2 = JTK_RANK_NONE; break; }
-        h2 = (h2 + 1) & mask;
-        s2 = t.slots[h2];
-    }
+    const uint32_t x1 = jtk_pair_match(v11, k1), y1 = jtk_pair_match(v12, k1);
+    const uint32_t x2 = jtk_pair_match(v21, k2), y2 = jtk_pair_match(v22, k2);
+    r1 = want1 ? (x1 != JTK_RANK_NONE ? x1 : y1) : JTK_RANK_NONE;
+    r2 = want2 ? (x2 != JTK_RANK_NONE ? x2 : y2) : JTK_RANK_NONE;
 }
 
 // ---- whole-piece table for pieces of <= 8 bytes -------------------------------------------------------
 // GptBytePairEncoding.java:81-83: a piece that is itself a table entry encodes to that one token.
 // Key = the piece's bytes, little-endian in (lo, hi), zero padded, plus its length.  16-byte slots,
-// open addressing; len == 0 marks an empty slot.
+// two-choice cuckoo (one slot per choice): a lookup is two independent 16-byte loads.
 struct JtkTok8Slot {
-    uint32_t lo, hi, id, len;
+    uint32_t lo, hi, id, len;       // len == 0: empty
 };
 struct JtkTok8Table {
     const JtkTok8Slot* slots;
@@ -105,6 +113,13 @@ JTK_HD uint32_t jtk_tok8_hash(uint32_t lo, uint32_t hi, uint32_t len, uint32_t b
     uint32_t h = lo * 0x9E3779B1u + (hi ^ (len << 27)) * 0x85EBCA77u;
     h ^= h >> 16;
     h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h >> (32 - bits);
+}
+JTK_HD uint32_t jtk_tok8_hash2(uint32_t lo, uint32_t hi, uint32_t len, uint32_t bits) {
+    uint32_t h = (lo ^ (len << 29)) * 0xC2B2AE3Du + hi * 0x27D4EB2Fu + 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
     h ^= h >> 13;
     return h >> (32 - bits);
 }

@@ -420,11 +420,10 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     // one lane per piece, four rounds of table probes in flight per lane
     const int64_t next_after = s_next_after;
     const JtkTok8Slot* t8 = t.tok8.slots;
-    const uint32_t t8mask = (1u << t.tok8.bits) - 1u;
     uint32_t* const h16 = w.hard16 + tile * JTK_HARD16_CAP;
     uint32_t* const h64 = w.hard64 + tile * JTK_HARD64_CAP;
     uint32_t my_hits = 0;
-    struct Probe { int s, len; uint32_t lo, hi, h, sx, sy, sz, sw; };
+    struct Probe { int s, len; uint32_t lo, hi, ax, ay, az, aw, bx, by, bz, bw; };
     auto issue = [&](int k, Probe& pr) {
         pr.s = -1; pr.len = 0;
         if (k < np) {
@@ -437,9 +436,10 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         }
         if (pr.s >= 0 && pr.len <= 8) {
             piece_key(s_tx, pr.s, pr.len, pr.lo, pr.hi);
-            pr.h = jtk_tok8_hash(pr.lo, pr.hi, (uint32_t)pr.len, t.tok8.bits);
-            const uint4 v = *reinterpret_cast<const uint4*>(&t8[pr.h]);
-            pr.sx = v.x; pr.sy = v.y; pr.sz = v.z; pr.sw = v.w;
+            const uint4 va = *reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash(pr.lo, pr.hi, (uint32_t)pr.len, t.tok8.bits)]);
+            const uint4 vb = *reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash2(pr.lo, pr.hi, (uint32_t)pr.len, t.tok8.bits)]);
+            pr.ax = va.x; pr.ay = va.y; pr.az = va.z; pr.aw = va.w;
+            pr.bx = vb.x; pr.by = vb.y; pr.bz = vb.z; pr.bw = vb.w;
         }
     };
     auto resolve = [&](int k, const Probe& pr) {
@@ -447,15 +447,9 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         if (pr.s >= 0) {
             const int s = pr.s, len = pr.len;
             if (len <= 8) {
-                uint4 sl = make_uint4(pr.sx, pr.sy, pr.sz, pr.sw);
-                uint32_t h = pr.h;
                 uint32_t id = JTK_RANK_NONE;
-                for (;;) {
-                    if (sl.w == (uint32_t)len && sl.x == pr.lo && sl.y == pr.hi) { id = sl.z; break; }
-                    if (sl.w == 0) break;
-                    h = (h + 1) & t8mask;
-                    sl = *reinterpret_cast<const uint4*>(&t8[h]);
-                }
+                if (pr.aw == (uint32_t)len && pr.ax == pr.lo && pr.ay == pr.hi) id = pr.az;
+                else if (pr.bw == (uint32_t)len && pr.bx == pr.lo && pr.by == pr.hi) id = pr.bz;
                 if (id != JTK_RANK_NONE) { s_id[s] = id; my_hits++; } else q16 = true;
             } else if (len <= 16) {
                 q16 = true;

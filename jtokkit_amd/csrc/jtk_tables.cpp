@@ -121,45 +121,88 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
     }
     t.n_pairs = (int64_t)pairs.size();
-    uint32_t bits = 10;
-    while ((1ull << bits) < pairs.size() * 2 + 16) bits++;
-    t.pair_bits = bits;
-    t.pair_slots.assign((size_t)1 << bits, JTK_PAIR_EMPTY);
-    const uint32_t mask = (1u << bits) - 1;
-    for (auto& p : pairs) {
-        const uint32_t a = (uint32_t)(p.first >> JTK_ID_BITS), b = (uint32_t)(p.first & ((1u << JTK_ID_BITS) - 1));
-        uint32_t h = jtk_pair_hash(a, b, bits);
-        while (t.pair_slots[h] != JTK_PAIR_EMPTY) h = (h + 1) & mask;
-        t.pair_slots[h] = (p.first << 30) | p.second;
+    // two-choice cuckoo, two slots per bucket; random-walk insertion
+    {
+        uint32_t bits = 8;
+        while ((1ull << bits) * 2 * 9 < pairs.size() * 20 + 64) bits++;      // load factor <= 0.45
+        for (;; bits++) {
+            std::vector<uint64_t> slots((size_t)2 << bits, JTK_PAIR_EMPTY);
+            uint32_t rng = 0x12345u;
+            bool ok = true;
+            for (auto& p : pairs) {
+                uint64_t cur = (p.first << 30) | p.second;
+                bool placed = false;
+                for (int kick = 0; kick < 2000 && !placed; kick++) {
+                    const uint64_t key = cur >> 30;
+                    const uint32_t a = (uint32_t)(key >> JTK_ID_BITS), b = (uint32_t)(key & ((1u << JTK_ID_BITS) - 1));
+                    const uint32_t bk[2] = {jtk_pair_hash(a, b, bits), jtk_pair_hash2(a, b, bits)};
+                    for (int c = 0; c < 2 && !placed; c++)
+                        for (int sidx = 0; sidx < 2 && !placed; sidx++)
+                            if (slots[(size_t)bk[c] * 2 + sidx] == JTK_PAIR_EMPTY) { slots[(size_t)bk[c] * 2 + sidx] = cur; placed = true; }
+                    if (!placed) {
+                        rng = rng * 1664525u + 1013904223u;
+                        const size_t victim = (size_t)bk[(rng >> 16) & 1] * 2 + ((rng >> 17) & 1);
+                        std::swap(cur, slots[victim]);
+                    }
+                }
+                if (!placed) { ok = false; break; }
+            }
+            if (!ok) continue;
+            t.pair_bits = bits;
+            t.pair_buckets.resize((size_t)1 << bits);
+            for (size_t k = 0; k < t.pair_buckets.size(); k++) {
+                const uint64_t s0 = slots[2 * k], s1 = slots[2 * k + 1];
+                t.pair_buckets[k] = JtkPairBucket{(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32)};
+            }
+            break;
+        }
     }
 
-    // whole-piece table (<= 8 bytes) and direct byte-pair table
+    // whole-piece table (<= 8 bytes, two-choice cuckoo) and direct byte-pair table
     t.bp_rank.assign(65536, JTK_RANK_NONE);
-    std::vector<const std::pair<const std::string, uint32_t>*> shorts;
+    std::vector<JtkTok8Slot> shorts;
     for (auto& kv : t.bytes_to_id) {
-        if (kv.first.size() <= 8) shorts.push_back(&kv);
-        if (kv.first.size() == 2) t.bp_rank[((uint32_t)(uint8_t)kv.first[0] << 8) | (uint8_t)kv.first[1]] = kv.second;
-    }
-    t.n_tok8 = (int64_t)shorts.size();
-    uint32_t b8 = 10;
-    while ((1ull << b8) * 5 < shorts.size() * 8 + 64) b8++;            // load factor <= 0.625
-    t.tok8_bits = b8;
-    t.tok8.assign((size_t)1 << b8, JtkTok8Slot{0, 0, 0, 0});
-    for (auto* kv : shorts) {
+        const std::string& T = kv.first;
+        if (T.size() == 2) t.bp_rank[((uint32_t)(uint8_t)T[0] << 8) | (uint8_t)T[1]] = kv.second;
+        if (T.size() > 8) continue;
         uint32_t lo = 0, hi = 0;
-        const std::string& T = kv->first;
         for (size_t k = 0; k < T.size(); k++) {
             if (k < 4) lo |= (uint32_t)(uint8_t)T[k] << (8 * k); else hi |= (uint32_t)(uint8_t)T[k] << (8 * (k - 4));
         }
-        uint32_t h = jtk_tok8_hash(lo, hi, (uint32_t)T.size(), b8);
-        while (t.tok8[h].len != 0) h = (h + 1) & ((1u << b8) - 1);
-        t.tok8[h] = JtkTok8Slot{lo, hi, kv->second, (uint32_t)T.size()};
+        shorts.push_back(JtkTok8Slot{lo, hi, kv.second, (uint32_t)T.size()});
+    }
+    t.n_tok8 = (int64_t)shorts.size();
+    {
+        uint32_t b8 = 8;
+        while ((1ull << b8) * 4 < shorts.size() * 10 + 64) b8++;           // load factor <= 0.4
+        for (;; b8++) {
+            std::vector<JtkTok8Slot> slots((size_t)1 << b8, JtkTok8Slot{0, 0, 0, 0});
+            uint32_t rng = 0x9876u;
+            bool ok = true;
+            for (auto cur : shorts) {
+                bool placed = false;
+                for (int kick = 0; kick < 2000 && !placed; kick++) {
+                    const uint32_t h[2] = {jtk_tok8_hash(cur.lo, cur.hi, cur.len, b8), jtk_tok8_hash2(cur.lo, cur.hi, cur.len, b8)};
+                    for (int c = 0; c < 2 && !placed; c++)
+                        if (slots[h[c]].len == 0) { slots[h[c]] = cur; placed = true; }
+                    if (!placed) {
+                        rng = rng * 1664525u + 1013904223u;
+                        std::swap(cur, slots[h[(rng >> 16) & 1]]);
+                    }
+                }
+                if (!placed) { ok = false; break; }
+            }
+            if (!ok) continue;
+            t.tok8_bits = b8;
+            t.tok8 = slots;
+            break;
+        }
     }
 
     // The shortcut is applied only to pieces of <= 8 bytes on the device; everything else goes through
     // bytePairMerge.  That is only equivalent to GptBytePairEncoding.java:81-86 when merging any table
     // token on its own yields exactly that token.
-    JtkPairTable pt{t.pair_slots.data(), t.pair_bits};
+    JtkPairTable pt{t.pair_buckets.data(), t.pair_bits};
     std::vector<uint32_t> ids, rk;
     for (auto& kv : t.bytes_to_id) {
         const std::string& T = kv.first;

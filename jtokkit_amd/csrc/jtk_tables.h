@@ -22,7 +22,7 @@ struct JtkHostTables {
     uint32_t tok8_bits = 0;
     int64_t n_tok8 = 0;
     std::vector<uint32_t> bp_rank;               // [65536] rank of the 2-byte token (b0 << 8 | b1), or NONE
-    std::vector<uint64_t> pair_slots;            // open-addressed (left,right) -> rank table
+    std::vector<JtkPairBucket> pair_buckets;     // two-choice cuckoo (left,right) -> rank table
     uint32_t pair_bits = 0;
     int64_t n_pairs = 0;
     int64_t n_tokens = 0;

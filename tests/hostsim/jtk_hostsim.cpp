@@ -145,32 +145,23 @@ int64_t sim_tok8_lookup(void* h, const uint8_t* piece, int len) {
     if (len < 1 || len > 8) return -1;
     uint32_t lo = 0, hi = 0;
     for (int k = 0; k < len; k++) { if (k < 4) lo |= (uint32_t)piece[k] << (8 * k); else hi |= (uint32_t)piece[k] << (8 * (k - 4)); }
-    uint32_t hh = jtk_tok8_hash(lo, hi, (uint32_t)len, t->tok8_bits);
-    int probes = 0;
-    for (;;) {
-        const JtkTok8Slot& s = t->tok8[hh];
-        probes++;
-        if (s.len == (uint32_t)len && s.lo == lo && s.hi == hi) return s.id;
-        if (s.len == 0) return -1;
-        hh = (hh + 1) & ((1u << t->tok8_bits) - 1);
-    }
+    const JtkTok8Slot& s1 = t->tok8[jtk_tok8_hash(lo, hi, (uint32_t)len, t->tok8_bits)];
+    const JtkTok8Slot& s2 = t->tok8[jtk_tok8_hash2(lo, hi, (uint32_t)len, t->tok8_bits)];
+    if (s1.len == (uint32_t)len && s1.lo == lo && s1.hi == hi) return s1.id;
+    if (s2.len == (uint32_t)len && s2.lo == lo && s2.hi == hi) return s2.id;
+    return -1;
 }
 int sim_tok8_bits(void* h) { return (int)((JtkHostTables*)h)->tok8_bits; }
 int64_t sim_tok8_count(void* h) { return ((JtkHostTables*)h)->n_tok8; }
-// average probe count over all stored keys
+// fraction of buckets' slots in use
 double sim_tables_avg_probe(void* h) {
     JtkHostTables* t = (JtkHostTables*)h;
-    const uint32_t mask = (1u << t->pair_bits) - 1;
-    double tot = 0; int64_t n = 0;
-    for (size_t s = 0; s < t->pair_slots.size(); s++) {
-        uint64_t v = t->pair_slots[s];
-        if (v == JTK_PAIR_EMPTY) continue;
-        uint64_t key = v >> 30;
-        uint32_t a = (uint32_t)(key >> JTK_ID_BITS), b = (uint32_t)(key & ((1u << JTK_ID_BITS) - 1));
-        uint32_t h0 = jtk_pair_hash(a, b, t->pair_bits);
-        tot += ((s - h0) & mask) + 1; n++;
+    double used = 0;
+    for (auto& b : t->pair_buckets) {
+        if (!(b.s0lo == 0xFFFFFFFFu && b.s0hi == 0xFFFFFFFFu)) used++;
+        if (!(b.s1lo == 0xFFFFFFFFu && b.s1hi == 0xFFFFFFFFu)) used++;
     }
-    return tot / (double)n;
+    return used / (2.0 * (double)t->pair_buckets.size());
 }
 // bytePairMerge of one piece (len <= 64) with the device's lane algorithm
 int sim_merge_piece(void* h, const uint8_t* piece, int len, int32_t* out) {
@@ -178,7 +169,7 @@ int sim_merge_piece(void* h, const uint8_t* piece, int len, int32_t* out) {
     if (len < 1 || len > 64) return -1;
     uint32_t ids[64], rk[64];
     for (int i = 0; i < len; i++) ids[i] = t->byte_rank[piece[i]];
-    JtkPairTable pt{t->pair_slots.data(), t->pair_bits};
+    JtkPairTable pt{t->pair_buckets.data(), t->pair_bits};
     jtk_merge_piece_lane(ids, rk, len, pt);
     // the device's form (direct byte-pair table + paired lookups) must agree with the plain one
     uint32_t ids2[64], rk2[64];
