@@ -98,6 +98,26 @@ JTK_HD void jtk_pair_lookup2(const JtkPairTable& t, uint32_t a1, uint32_t b1, bo
     r2 = want2 ? (x2 != JTK_RANK_NONE ? x2 : y2) : JTK_RANK_NONE;
 }
 
+// ---- 2-byte tokens, compressed for LDS: rank of (b0, b1) = ranks[cum[i >> 6] + popcount(bits[i >> 6] below i)]
+#define JTK_BP_MAX 4096
+struct JtkBpLds {
+    const uint64_t* bits;     // [1024]
+    const uint16_t* cum;      // [1024]
+    const uint32_t* ranks;    // [JTK_BP_MAX]
+};
+JTK_HD uint32_t jtk_bp_lookup(const JtkBpLds& t, uint32_t idx) {
+    const uint64_t wbits = t.bits[idx >> 6];
+    const uint32_t j = idx & 63u;
+    if (!((wbits >> j) & 1ull)) return JTK_RANK_NONE;
+    const uint64_t below = wbits & ((1ull << j) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k = (uint32_t)__popcll((unsigned long long)below);
+#else
+    const uint32_t k = (uint32_t)__builtin_popcountll(below);
+#endif
+    return t.ranks[t.cum[idx >> 6] + k];
+}
+
 // ---- whole-piece table for pieces of <= 8 bytes -------------------------------------------------------
 // GptBytePairEncoding.java:81-83: a piece that is itself a table entry encodes to that one token.
 // Key = the piece's bytes, little-endian in (lo, hi), zero padded, plus its length.  16-byte slots,

@@ -12,7 +12,7 @@
 #define JTK_TILE 2048            // bytes per piece_resolve / pack workgroup; token counts are kept per tile
 #define JTK_HARD16_CAP 1024      // per tile: pieces of 2..16 bytes queued for bytePairMerge (>= JTK_TILE / 2)
 #define JTK_HARD64_CAP 128       // per tile: pieces of 17..64 bytes (>= JTK_TILE / 17)
-#define JTK_HARD_GROUP 12         // tiles whose queues one merge workgroup drains
+#define JTK_HARD_GROUP 8         // tiles whose queues one merge workgroup drains
 #define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
 #define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin (= JTK_MAX_PIECE_BYTES)
 #define JTK_MAX_SPECIALS 8
@@ -24,6 +24,7 @@ struct JtkDeviceTables {
     JtkPairTable pairs;
     JtkTok8Table tok8;
     const uint32_t* bp_rank;     // [65536]
+    JtkBpLds bp;                 // the same, compressed (staged into LDS by bpe_merge)
     int kind;
     int n_specials;
     uint8_t special_len[JTK_MAX_SPECIALS];

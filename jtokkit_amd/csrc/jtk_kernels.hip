@@ -627,6 +627,211 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
 }
 
 // ---------------------------------------------------------------------------------------------------
+// bpe_merge16: the common case (pieces of 2..16 bytes that are not single tokens), built around what
+// bounds it -- dependent table lookups.  Per lane a small state machine: NEED -> (queue entry) ->
+// TEXT -> (16 text bytes) -> MERGE ... -> emit.  Every trip of the loop each lane issues the loads of
+// its current state, then the wave waits ONCE, so a piece costs (2 + merges) round trips and a wave
+// keeps 64 independent chains in flight.  The parts of a piece (ids and pair ranks) live in 32
+// REGISTERS per lane (all indices unrolled), which leaves LDS to the tables: the byte -> rank table and
+// the complete 2-byte-token table (bitmap + ranks) are staged in LDS, so setting a piece up needs no
+// global lookups; only the (left id, right id) pair table is read from L2.
+// Leftmost-minimum (GptBytePairEncoding.java:236): min over key = rank << 4 | slot.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t RKP_NONE = 0xFFFFFFFFu;
+
+// a[i] for a register-resident array: a 4-level tree of bitwise selects (v_bfi), written with masks so
+// that the compiler does not turn it back into an indexed (scratch) access.
+__device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t x1, uint32_t x0) { return (x1 & m) | (x0 & ~m); }
+__device__ __forceinline__ uint32_t sel16(const uint32_t (&a)[16], uint32_t i) {
+    const uint32_t m0 = 0u - (i & 1u), m1 = 0u - ((i >> 1) & 1u), m2 = 0u - ((i >> 2) & 1u), m3 = 0u - ((i >> 3) & 1u);
+    uint32_t t8[8], t4[4], t2[2];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t8[k] = bsel(m0, a[2 * k + 1], a[2 * k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) t4[k] = bsel(m1, t8[2 * k + 1], t8[2 * k]);
+#pragma unroll
+    for (int k = 0; k < 2; k++) t2[k] = bsel(m2, t4[2 * k + 1], t4[2 * k]);
+    return bsel(m3, t2[1], t2[0]);
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) k_bpe_merge16(JtkWork w, JtkDeviceTables t) {
+    __shared__ uint64_t s_bpbits[1024];
+    __shared__ uint32_t s_bpranks[JTK_BP_MAX];
+    __shared__ uint16_t s_bpcum[1024];
+    __shared__ uint32_t s_brank[256];
+    __shared__ uint32_t s_tc[JTK_HARD_GROUP + 1];
+    __shared__ uint32_t s_next;
+    constexpr int G = JTK_HARD_GROUP;
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    // the workgroup drains the queues of its G consecutive tiles; its four waves share one cursor
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    uint32_t pre[G + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int g = 0; g < G; g++) pre[g + 1] = pre[g] + ((g0 + g < w.n_tiles) ? w.n_hard16[g0 + g] : 0u);
+    const uint32_t total = pre[G];
+    if (total == 0) return;
+
+    for (int i = tid; i < 1024; i += 256) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
+    for (int i = tid; i < JTK_BP_MAX; i += 256) s_bpranks[i] = t.bp.ranks[i];
+    s_brank[tid] = t.byte_rank[tid];
+    if (tid <= G) s_tc[tid] = 0;
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    const JtkBpLds bp{s_bpbits, s_bpcum, s_bpranks};
+    const JtkPairTable pt = t.pairs;
+
+    // NEED -> TEXT -> EXPAND -> MERGE ... -> EMIT -> NEED.  The two expensive, divergent steps (EXPAND: bytes
+    // -> ids and pair ranks through the LDS tables; EMIT: scatter the tokens) only run once enough lanes
+    // wait for them, so that their instructions are amortised over many lanes.
+    enum { ST_NEED = 0, ST_TEXT = 1, ST_EXPAND = 2, ST_MERGE = 3, ST_EMIT = 4, ST_DONE = 5 };
+    constexpr int BATCH = 24;
+    int st = ST_NEED;
+    uint32_t qi = 0;
+    int64_t pos = 0;
+    int g = 0, len = 0;
+    uint32_t alive = 0;
+    uint32_t id[16], rkp[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { id[j] = 0; rkp[j] = RKP_NONE; }
+
+    for (;;) {
+        // (1) merging lanes pick their pair
+        uint32_t minr = 0, mini = 0, nxt = 0, nn = 0, pv = 0;
+        bool has_nn = false, has_pv = false, merging = false;
+        if (st == ST_MERGE) {
+            uint32_t m = rkp[0];
+#pragma unroll
+            for (int j = 1; j < 16; j++) m = min(m, rkp[j]);                                 // :234-240
+            if (m != RKP_NONE) {                                                             // :247
+                merging = true;
+                minr = m >> 4; mini = m & 15u;
+                const uint32_t above = alive & ~((2u << mini) - 1u);
+                nxt = (uint32_t)__ffs((int)above) - 1u;
+                const uint32_t above2 = above & (above - 1u);
+                has_nn = above2 != 0;
+                nn = has_nn ? (uint32_t)__ffs((int)above2) - 1u : 0u;
+                const uint32_t below = alive & ((1u << mini) - 1u);
+                has_pv = below != 0;
+                pv = has_pv ? 31u - (uint32_t)__clz((int)below) : 0u;
+            } else st = ST_EMIT;                                                             // :261
+        }
+        const uint64_t b_merge = __ballot(merging);
+        // (2) emit finished pieces (:270-273) once a batch has gathered, or when nothing else would run
+        const uint64_t b_emit = __ballot(st == ST_EMIT);
+        if (b_emit && (__popcll(b_emit) >= BATCH || !b_merge)) {
+            if (st == ST_EMIT) {
+                const int64_t tile_end = (g0 + g + 1) * (int64_t)T;
+                uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if ((alive >> j) & 1u) {
+                        w.tok_at[pos + j] = id[j];
+                        if (pos + j < tile_end) c0++; else c1++;
+                    }
+                }
+                atomicAdd(&s_tc[g], c0);
+                if (c1) atomicAdd(&s_tc[g + 1], c1);
+                st = ST_NEED;
+            }
+        }
+        // (3) idle lanes take the next queue entries
+        const uint64_t want = __ballot(st == ST_NEED);
+        if (want) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, (uint32_t)__popcll(want));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (st == ST_NEED) {
+                qi = base + (uint32_t)__popcll(want & lanemask_lt());
+                if (qi >= total) st = ST_DONE;
+            }
+        }
+        if (!__ballot(st != ST_DONE)) break;
+
+        // (4) all loads of this trip
+        uint32_t entry = 0;
+        uint4 ta = make_uint4(0, 0, 0, 0), tb = make_uint4(0, 0, 0, 0);
+        JtkPairBucket b11, b12, b21, b22;
+        b11.s0lo = b11.s0hi = b11.s1lo = b11.s1hi = 0xFFFFFFFFu;
+        b12 = b11; b21 = b11; b22 = b11;
+        uint32_t idnn = 0, idpv = 0;
+        if (st == ST_NEED) {
+            g = 0;
+            uint32_t gbase = 0;
+#pragma unroll
+            for (int q = 1; q < G; q++) if (qi >= pre[q]) { g = q; gbase = pre[q]; }
+            entry = w.hard16[(g0 + g) * JTK_HARD16_CAP + (qi - gbase)];
+        } else if (st == ST_TEXT) {
+            const int64_t base = pos & ~(int64_t)15;
+            ta = *reinterpret_cast<const uint4*>(w.text + base);
+            if (base + 16 < w.n_bytes) tb = *reinterpret_cast<const uint4*>(w.text + base + 16);
+        } else if (merging) {
+            idnn = sel16(id, nn);
+            idpv = sel16(id, pv);
+            if (has_nn) { b11 = pt.buckets[jtk_pair_hash(minr, idnn, pt.bits)]; b12 = pt.buckets[jtk_pair_hash2(minr, idnn, pt.bits)]; }
+            if (has_pv) { b21 = pt.buckets[jtk_pair_hash(idpv, minr, pt.bits)]; b22 = pt.buckets[jtk_pair_hash2(idpv, minr, pt.bits)]; }
+        }
+
+        // (5) consume
+        if (st == ST_NEED) {
+            pos = (g0 + g) * (int64_t)T + (entry & 4095u);
+            len = (int)(entry >> 12);
+            st = ST_TEXT;
+        } else if (st == ST_TEXT) {
+            // park the 32-byte window in the (idle) part registers until the expansion batch runs
+            id[0] = ta.x; id[1] = ta.y; id[2] = ta.z; id[3] = ta.w; id[4] = tb.x; id[5] = tb.y; id[6] = tb.z; id[7] = tb.w;
+            st = ST_EXPAND;
+        } else if (merging) {
+            const uint64_t k1 = jtk_pair_key(minr, idnn), k2 = jtk_pair_key(idpv, minr);
+            uint32_t r1 = JTK_RANK_NONE, r2 = JTK_RANK_NONE;
+            if (has_nn) { const uint32_t x = jtk_pair_match(b11, k1), y = jtk_pair_match(b12, k1); r1 = x != JTK_RANK_NONE ? x : y; }
+            if (has_pv) { const uint32_t x = jtk_pair_match(b21, k2), y = jtk_pair_match(b22, k2); r2 = x != JTK_RANK_NONE ? x : y; }
+            const uint32_t new_mini = (r1 == JTK_RANK_NONE) ? RKP_NONE : ((r1 << 4) | mini);   // :254
+            const uint32_t new_pv = (r2 == JTK_RANK_NONE) ? RKP_NONE : ((r2 << 4) | pv);       // :255-257
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                uint32_t v = rkp[j];
+                if (has_pv && (uint32_t)j == pv) v = new_pv;
+                if ((uint32_t)j == mini) v = new_mini;
+                if ((uint32_t)j == nxt) v = RKP_NONE;
+                rkp[j] = v;
+                if ((uint32_t)j == mini) id[j] = minr;
+            }
+            alive &= ~(1u << nxt);                                                             // :259
+        }
+        // (6) expand parked pieces: 16 bytes at `pos` -> single-byte ids and 2-byte-token ranks (:206-221)
+        const uint64_t b_exp = __ballot(st == ST_EXPAND);
+        if (b_exp && (__popcll(b_exp) >= BATCH || !__ballot(st == ST_MERGE))) {
+            if (st == ST_EXPAND) {
+                const uint32_t off = (uint32_t)(pos & 15), q = off >> 2, sh = off & 3u;
+                uint32_t e1[7], e2[5], o[4];
+#pragma unroll
+                for (int k = 0; k < 7; k++) e1[k] = bsel(0u - (q & 1u), id[k + 1], id[k]);
+#pragma unroll
+                for (int k = 0; k < 5; k++) e2[k] = bsel(0u - ((q >> 1) & 1u), e1[k + 2], e1[k]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_alignbyte(e2[k + 1], e2[k], sh);
+                uint32_t by[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) by[j] = (o[j >> 2] >> (8 * (j & 3))) & 255u;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    id[j] = s_brank[by[j]];
+                    uint32_t r = JTK_RANK_NONE;
+                    if (j + 1 < 16 && j + 1 < len) r = jtk_bp_lookup(bp, (by[j] << 8) | by[(j + 1) & 15]);
+                    rkp[j] = (r == JTK_RANK_NONE) ? RKP_NONE : ((r << 4) | (uint32_t)j);
+                }
+                alive = (1u << len) - 1u;
+                st = ST_MERGE;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid <= G && s_tc[tid] && g0 + tid < w.n_tiles) atomicAdd(&w.tile_cnt[g0 + tid], s_tc[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // bpe_merge_long: one wave per piece of 65..8192 bytes.  Every lane scans a stride of the parts;
 // leftmost-minimum selection is a wave reduction on key = rank << 13 | position (positions < 8192),
 // which orders by rank first and by position among equal ranks (GptBytePairEncoding.java:236).
@@ -810,7 +1015,7 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     const unsigned groups = (unsigned)((w.n_tiles + JTK_HARD_GROUP - 1) / JTK_HARD_GROUP);
-    hipLaunchKernelGGL((k_bpe_merge<16, 256>), dim3(groups), dim3(256), 0, s, w, t);
+    hipLaunchKernelGGL(k_bpe_merge16, dim3(groups), dim3(256), 0, s, w, t);
     hipLaunchKernelGGL((k_bpe_merge<64, 64>), dim3(groups), dim3(64), 0, s, w, t);
 }
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {

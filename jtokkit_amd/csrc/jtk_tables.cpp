@@ -173,6 +173,20 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
     }
     t.n_tok8 = (int64_t)shorts.size();
     {
+        t.bp_bits.assign(1024, 0);
+        t.bp_cum.assign(1024, 0);
+        t.bp_ranks.assign(JTK_BP_MAX, JTK_RANK_NONE);
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < 65536; i++) {
+            if ((i & 63u) == 0) t.bp_cum[i >> 6] = (uint16_t)k;
+            if (t.bp_rank[i] != JTK_RANK_NONE) {
+                if (k >= JTK_BP_MAX) { err = "too many 2-byte tokens for the LDS table"; return JTK_ERR_UNSUPPORTED_TABLE; }
+                t.bp_bits[i >> 6] |= 1ull << (i & 63u);
+                t.bp_ranks[k++] = t.bp_rank[i];
+            }
+        }
+    }
+    {
         uint32_t b8 = 8;
         while ((1ull << b8) * 4 < shorts.size() * 10 + 64) b8++;           // load factor <= 0.4
         for (;; b8++) {

@@ -22,6 +22,10 @@ struct JtkHostTables {
     uint32_t tok8_bits = 0;
     int64_t n_tok8 = 0;
     std::vector<uint32_t> bp_rank;               // [65536] rank of the 2-byte token (b0 << 8 | b1), or NONE
+    // the same table compressed for LDS: membership bitmap, per-word running count, ranks in index order
+    std::vector<uint64_t> bp_bits;               // [1024]
+    std::vector<uint16_t> bp_cum;                // [1024]
+    std::vector<uint32_t> bp_ranks;              // [n_bp] (padded to JTK_BP_MAX)
     std::vector<JtkPairBucket> pair_buckets;     // two-choice cuckoo (left,right) -> rank table
     uint32_t pair_bits = 0;
     int64_t n_pairs = 0;
