@@ -234,7 +234,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
 
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
-    const size_t zero_bytes = mask_bytes + status_bytes + 32;
+    const size_t zero_bytes = mask_bytes + status_bytes + 32 + JTK_Q_SHARDS * 4;
     const size_t nt = (size_t)w.n_tiles;
     const size_t n_long_max = (size_t)n_bytes / 65 + 2;
     int rc;
@@ -242,8 +242,8 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
         (rc = b->tokmask.ensure(mask_bytes)) || (rc = b->blk_pre.ensure((size_t)w.n_words * 2)) ||
         (rc = b->tok_at.ensure(nt * JTK_TILE * 4)) ||
         (rc = b->tile_cnt.ensure(nt * 4)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
-        (rc = b->hard16.ensure(nt * JTK_HARD16_CAP * 4)) || (rc = b->hard64.ensure(nt * JTK_HARD64_CAP * 4)) ||
-        (rc = b->n_hard.ensure(nt * 8)) ||
+        (rc = b->hard16.ensure(((nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS) * JTK_HARD16_CAP * JTK_Q_SHARDS * 8)) || (rc = b->hard64.ensure(nt * JTK_HARD64_CAP * 4)) ||
+        (rc = b->n_hard.ensure(nt * 4)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
@@ -261,10 +261,11 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.tok_at = (uint32_t*)b->tok_at.p;
     w.tile_cnt = (uint32_t*)b->tile_cnt.p;
     w.tile_off = (int64_t*)b->tile_off.p;
-    w.hard16 = (uint32_t*)b->hard16.p;
+    w.q16 = (uint64_t*)b->hard16.p;
+    w.q16_cap = (int64_t)((nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS) * JTK_HARD16_CAP;
+    w.q16_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
     w.hard64 = (uint32_t*)b->hard64.p;
-    w.n_hard16 = (uint32_t*)b->n_hard.p;
-    w.n_hard64 = (uint32_t*)b->n_hard.p + nt;
+    w.n_hard64 = (uint32_t*)b->n_hard.p;
     w.mid_list = (JtkLongPiece*)b->mid_list.p;
     w.long_list = (JtkLongPiece*)b->long_list.p;
     w.tokens = (int32_t*)b->tokens.p;

@@ -11,6 +11,9 @@
 #define JTK_SPLIT_HALO 64
 #define JTK_TILE 2048            // bytes per piece_resolve / pack workgroup; token counts are kept per tile
 #define JTK_HARD16_CAP 1024      // per tile: pieces of 2..16 bytes queued for bytePairMerge (>= JTK_TILE / 2)
+#define JTK_Q_SHARDS 64          // dense merge queues: tile t appends to shard t % 64 (one atomic per tile)
+#define JTK_M16_THREADS 1024     // bpe_merge16 workgroup (one per CU; its LDS holds the parts of 1024 pieces)
+#define JTK_M16_WGS_PER_SHARD 4
 #define JTK_HARD64_CAP 128       // per tile: pieces of 17..64 bytes (>= JTK_TILE / 17)
 #define JTK_HARD_GROUP 8         // tiles whose queues one merge workgroup drains
 #define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
@@ -57,9 +60,10 @@ struct JtkWork {
     uint32_t* tok_at;       // per byte position: id of the token starting there, or JTK_ID_DEAD
     uint32_t* tile_cnt;     // tokens starting in each tile
     int64_t* tile_off;      // exclusive scan of tile_cnt (n_tiles + 1)
-    uint32_t* hard16;       // [n_tiles][JTK_HARD16_CAP]  offset-in-tile | len << 12
+    uint64_t* q16;          // [JTK_Q_SHARDS][q16_cap] pieces of 2..16 bytes queued for bytePairMerge: pos | len << 40
+    uint32_t* q16_count;    // [JTK_Q_SHARDS]
+    int64_t q16_cap;        // entries per shard
     uint32_t* hard64;       // [n_tiles][JTK_HARD64_CAP]
-    uint32_t* n_hard16;     // [n_tiles]
     uint32_t* n_hard64;     // [n_tiles]
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces

@@ -376,7 +376,8 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __shared__ uint64_t s_pm[TW];
     __shared__ uint32_t s_cnt[TW];
     __shared__ uint32_t s_pre[TW + 1];
-    __shared__ uint32_t s_n16, s_n64, s_hits;
+    __shared__ uint64_t s_q16[JTK_HARD16_CAP];   // this tile's pieces for bpe_merge16
+    __shared__ uint32_t s_n16, s_n64, s_hits, s_qbase;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -420,7 +421,6 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     // one lane per piece, four rounds of table probes in flight per lane
     const int64_t next_after = s_next_after;
     const JtkTok8Slot* t8 = t.tok8.slots;
-    uint32_t* const h16 = w.hard16 + tile * JTK_HARD16_CAP;
     uint32_t* const h64 = w.hard64 + tile * JTK_HARD64_CAP;
     uint32_t my_hits = 0;
     struct Probe { int s, len; uint32_t lo, hi, ax, ay, az, aw, bx, by, bz, bw; };
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&s_n16, (uint32_t)__popcll(bal));
             base = (uint32_t)__shfl((int)base, 0);
-            if (q16) h16[base + __popcll(bal & lanemask_lt())] = entry;
+            if (q16) s_q16[base + __popcll(bal & lanemask_lt())] = (uint64_t)(B + pr.s) | ((uint64_t)pr.len << 40);
         }
         bal = __ballot(q64);
         if (bal) {
@@ -494,7 +494,16 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __syncthreads();
     for (int i = tid; i < T / 4; i += 256)
         reinterpret_cast<uint4*>(w.tok_at + B)[i] = reinterpret_cast<const uint4*>(s_id)[i];
-    if (tid == 0) { w.tile_cnt[tile] = s_hits; w.n_hard16[tile] = s_n16; w.n_hard64[tile] = s_n64; }
+    if (tid == 0) {
+        w.tile_cnt[tile] = s_hits;
+        w.n_hard64[tile] = s_n64;
+        s_qbase = s_n16 ? atomicAdd(&w.q16_count[tile % JTK_Q_SHARDS], s_n16) : 0u;   // one returning atomic per tile
+    }
+    __syncthreads();
+    {
+        uint64_t* q = w.q16 + (tile % JTK_Q_SHARDS) * w.q16_cap + s_qbase;
+        for (uint32_t i = tid; i < s_n16; i += 256) q[i] = s_q16[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -513,8 +522,9 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     constexpr int G = JTK_HARD_GROUP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t g0 = (int64_t)blockIdx.x * G;
-    const uint32_t* list = (SLOTS == 16) ? w.hard16 : w.hard64;
-    const uint32_t* cnts = (SLOTS == 16) ? w.n_hard16 : w.n_hard64;
+    static_assert(SLOTS == 64, "pieces of <= 16 bytes go to k_bpe_merge16");
+    const uint32_t* list = w.hard64;
+    const uint32_t* cnts = w.n_hard64;
     constexpr int CAP = (SLOTS == 16) ? JTK_HARD16_CAP : JTK_HARD64_CAP;
 
     uint32_t pre[G + 1];                       // only ever indexed by unrolled constants
@@ -654,56 +664,54 @@ __device__ __forceinline__ uint32_t sel16(const uint32_t (&a)[16], uint32_t i) {
     return bsel(m3, t2[1], t2[0]);
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) k_bpe_merge16(JtkWork w, JtkDeviceTables t) {
+constexpr int M16T = JTK_M16_THREADS;
+constexpr int M16_CHUNK = 2048;                // queue entries a workgroup takes at a time
+
+__global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables t) {
+    __shared__ uint32_t s_id[16 * M16T];       // parts of the pieces in flight, [slot][lane]: conflict free
+    __shared__ uint32_t s_rk[16 * M16T];       //   for any per-lane slot index
     __shared__ uint64_t s_bpbits[1024];
     __shared__ uint32_t s_bpranks[JTK_BP_MAX];
     __shared__ uint16_t s_bpcum[1024];
     __shared__ uint32_t s_brank[256];
-    __shared__ uint32_t s_tc[JTK_HARD_GROUP + 1];
     __shared__ uint32_t s_next;
-    constexpr int G = JTK_HARD_GROUP;
     const int tid = threadIdx.x, lane = tid & 63;
 
-    // the workgroup drains the queues of its G consecutive tiles; its four waves share one cursor
-    const int64_t g0 = (int64_t)blockIdx.x * G;
-    uint32_t pre[G + 1];
-    pre[0] = 0;
-#pragma unroll
-    for (int g = 0; g < G; g++) pre[g + 1] = pre[g] + ((g0 + g < w.n_tiles) ? w.n_hard16[g0 + g] : 0u);
-    const uint32_t total = pre[G];
-    if (total == 0) return;
+    // dense queue shard `shard`; this workgroup takes chunks kq, kq + K, kq + 2K, ... of it
+    const int shard = blockIdx.x % JTK_Q_SHARDS;
+    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
+    const uint32_t count = w.q16_count[shard];
+    if ((uint64_t)kq * M16_CHUNK >= count) return;
+    const uint64_t* queue = w.q16 + (int64_t)shard * w.q16_cap;
 
-    for (int i = tid; i < 1024; i += 256) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
-    for (int i = tid; i < JTK_BP_MAX; i += 256) s_bpranks[i] = t.bp.ranks[i];
-    s_brank[tid] = t.byte_rank[tid];
-    if (tid <= G) s_tc[tid] = 0;
+    for (int i = tid; i < 1024; i += M16T) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
+    for (int i = tid; i < JTK_BP_MAX; i += M16T) s_bpranks[i] = t.bp.ranks[i];
+    if (tid < 256) s_brank[tid] = t.byte_rank[tid];
     if (tid == 0) s_next = 0;
     __syncthreads();
     const JtkBpLds bp{s_bpbits, s_bpcum, s_bpranks};
     const JtkPairTable pt = t.pairs;
+    uint32_t* const id = s_id + tid;
+    uint32_t* const rk = s_rk + tid;
 
-    // NEED -> TEXT -> EXPAND -> MERGE ... -> EMIT -> NEED.  The two expensive, divergent steps (EXPAND: bytes
-    // -> ids and pair ranks through the LDS tables; EMIT: scatter the tokens) only run once enough lanes
-    // wait for them, so that their instructions are amortised over many lanes.
+    // NEED -> TEXT -> EXPAND -> MERGE ... -> EMIT -> NEED.  Every trip each lane issues the loads of its state,
+    // the wave waits once; the two expensive divergent steps (EXPAND, EMIT) run when a batch has gathered.
     enum { ST_NEED = 0, ST_TEXT = 1, ST_EXPAND = 2, ST_MERGE = 3, ST_EMIT = 4, ST_DONE = 5 };
     constexpr int BATCH = 24;
     int st = ST_NEED;
     uint32_t qi = 0;
     int64_t pos = 0;
-    int g = 0, len = 0;
+    int len = 0;
     uint32_t alive = 0;
-    uint32_t id[16], rkp[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) { id[j] = 0; rkp[j] = RKP_NONE; }
 
     for (;;) {
-        // (1) merging lanes pick their pair
-        uint32_t minr = 0, mini = 0, nxt = 0, nn = 0, pv = 0;
+        // (1) merging lanes pick their pair: leftmost minimum of rank << 4 | slot (:234-240)
+        uint32_t minr = 0, mini = 0, nxt = 0, nn = 0, pv = 0, idnn = 0, idpv = 0;
         bool has_nn = false, has_pv = false, merging = false;
         if (st == ST_MERGE) {
-            uint32_t m = rkp[0];
+            uint32_t m = RKP_NONE;
 #pragma unroll
-            for (int j = 1; j < 16; j++) m = min(m, rkp[j]);                                 // :234-240
+            for (int j = 0; j < 16; j++) m = min(m, rk[j * M16T]);
             if (m != RKP_NONE) {                                                             // :247
                 merging = true;
                 minr = m >> 4; mini = m & 15u;
@@ -715,99 +723,92 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                 const uint32_t below = alive & ((1u << mini) - 1u);
                 has_pv = below != 0;
                 pv = has_pv ? 31u - (uint32_t)__clz((int)below) : 0u;
+                idnn = id[nn * M16T];
+                idpv = id[pv * M16T];
             } else st = ST_EMIT;                                                             // :261
         }
         const uint64_t b_merge = __ballot(merging);
-        // (2) emit finished pieces (:270-273) once a batch has gathered, or when nothing else would run
+        // (2) emit finished pieces (:270-273)
         const uint64_t b_emit = __ballot(st == ST_EMIT);
         if (b_emit && (__popcll(b_emit) >= BATCH || !b_merge)) {
             if (st == ST_EMIT) {
-                const int64_t tile_end = (g0 + g + 1) * (int64_t)T;
+                const int64_t tile = pos / T;
+                const int64_t tile_end = (tile + 1) * (int64_t)T;
                 uint32_t c0 = 0, c1 = 0;
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     if ((alive >> j) & 1u) {
-                        w.tok_at[pos + j] = id[j];
+                        w.tok_at[pos + j] = id[j * M16T];
                         if (pos + j < tile_end) c0++; else c1++;
                     }
                 }
-                atomicAdd(&s_tc[g], c0);
-                if (c1) atomicAdd(&s_tc[g + 1], c1);
+                atomicAdd(&w.tile_cnt[tile], c0);
+                if (c1) atomicAdd(&w.tile_cnt[tile + 1], c1);
                 st = ST_NEED;
             }
         }
-        // (3) idle lanes take the next queue entries
+        // (3) idle lanes take the next queue entries of this workgroup's chunks
         const uint64_t want = __ballot(st == ST_NEED);
         if (want) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&s_next, (uint32_t)__popcll(want));
             base = (uint32_t)__shfl((int)base, 0);
             if (st == ST_NEED) {
-                qi = base + (uint32_t)__popcll(want & lanemask_lt());
-                if (qi >= total) st = ST_DONE;
+                const uint32_t seq = base + (uint32_t)__popcll(want & lanemask_lt());
+                const uint64_t idx = (uint64_t)(kq + (seq / M16_CHUNK) * K) * M16_CHUNK + (seq % M16_CHUNK);
+                if (idx >= count) st = ST_DONE; else qi = (uint32_t)idx;
             }
         }
         if (!__ballot(st != ST_DONE)) break;
 
         // (4) all loads of this trip
-        uint32_t entry = 0;
+        uint64_t entry = 0;
         uint4 ta = make_uint4(0, 0, 0, 0), tb = make_uint4(0, 0, 0, 0);
         JtkPairBucket b11, b12, b21, b22;
         b11.s0lo = b11.s0hi = b11.s1lo = b11.s1hi = 0xFFFFFFFFu;
         b12 = b11; b21 = b11; b22 = b11;
-        uint32_t idnn = 0, idpv = 0;
-        if (st == ST_NEED) {
-            g = 0;
-            uint32_t gbase = 0;
-#pragma unroll
-            for (int q = 1; q < G; q++) if (qi >= pre[q]) { g = q; gbase = pre[q]; }
-            entry = w.hard16[(g0 + g) * JTK_HARD16_CAP + (qi - gbase)];
-        } else if (st == ST_TEXT) {
+        if (st == ST_NEED) entry = queue[qi];
+        else if (st == ST_TEXT) {
             const int64_t base = pos & ~(int64_t)15;
             ta = *reinterpret_cast<const uint4*>(w.text + base);
             if (base + 16 < w.n_bytes) tb = *reinterpret_cast<const uint4*>(w.text + base + 16);
         } else if (merging) {
-            idnn = sel16(id, nn);
-            idpv = sel16(id, pv);
             if (has_nn) { b11 = pt.buckets[jtk_pair_hash(minr, idnn, pt.bits)]; b12 = pt.buckets[jtk_pair_hash2(minr, idnn, pt.bits)]; }
             if (has_pv) { b21 = pt.buckets[jtk_pair_hash(idpv, minr, pt.bits)]; b22 = pt.buckets[jtk_pair_hash2(idpv, minr, pt.bits)]; }
         }
 
         // (5) consume
         if (st == ST_NEED) {
-            pos = (g0 + g) * (int64_t)T + (entry & 4095u);
-            len = (int)(entry >> 12);
+            pos = (int64_t)(entry & 0xFFFFFFFFFFull);
+            len = (int)(entry >> 40);
             st = ST_TEXT;
         } else if (st == ST_TEXT) {
-            // park the 32-byte window in the (idle) part registers until the expansion batch runs
-            id[0] = ta.x; id[1] = ta.y; id[2] = ta.z; id[3] = ta.w; id[4] = tb.x; id[5] = tb.y; id[6] = tb.z; id[7] = tb.w;
+            // park the 32-byte window in the (idle) part slots until the expansion batch runs
+            id[0 * M16T] = ta.x; id[1 * M16T] = ta.y; id[2 * M16T] = ta.z; id[3 * M16T] = ta.w;
+            id[4 * M16T] = tb.x; id[5 * M16T] = tb.y; id[6 * M16T] = tb.z; id[7 * M16T] = tb.w;
             st = ST_EXPAND;
         } else if (merging) {
             const uint64_t k1 = jtk_pair_key(minr, idnn), k2 = jtk_pair_key(idpv, minr);
             uint32_t r1 = JTK_RANK_NONE, r2 = JTK_RANK_NONE;
             if (has_nn) { const uint32_t x = jtk_pair_match(b11, k1), y = jtk_pair_match(b12, k1); r1 = x != JTK_RANK_NONE ? x : y; }
             if (has_pv) { const uint32_t x = jtk_pair_match(b21, k2), y = jtk_pair_match(b22, k2); r2 = x != JTK_RANK_NONE ? x : y; }
-            const uint32_t new_mini = (r1 == JTK_RANK_NONE) ? RKP_NONE : ((r1 << 4) | mini);   // :254
-            const uint32_t new_pv = (r2 == JTK_RANK_NONE) ? RKP_NONE : ((r2 << 4) | pv);       // :255-257
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                uint32_t v = rkp[j];
-                if (has_pv && (uint32_t)j == pv) v = new_pv;
-                if ((uint32_t)j == mini) v = new_mini;
-                if ((uint32_t)j == nxt) v = RKP_NONE;
-                rkp[j] = v;
-                if ((uint32_t)j == mini) id[j] = minr;
-            }
-            alive &= ~(1u << nxt);                                                             // :259
+            if (has_pv) rk[pv * M16T] = (r2 == JTK_RANK_NONE) ? RKP_NONE : ((r2 << 4) | pv);     // :255-257
+            rk[mini * M16T] = (r1 == JTK_RANK_NONE) ? RKP_NONE : ((r1 << 4) | mini);             // :254
+            rk[nxt * M16T] = RKP_NONE;
+            id[mini * M16T] = minr;
+            alive &= ~(1u << nxt);                                                               // :259
         }
         // (6) expand parked pieces: 16 bytes at `pos` -> single-byte ids and 2-byte-token ranks (:206-221)
         const uint64_t b_exp = __ballot(st == ST_EXPAND);
         if (b_exp && (__popcll(b_exp) >= BATCH || !__ballot(st == ST_MERGE))) {
             if (st == ST_EXPAND) {
+                uint32_t d[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = id[k * M16T];
                 const uint32_t off = (uint32_t)(pos & 15), q = off >> 2, sh = off & 3u;
                 uint32_t e1[7], e2[5], o[4];
 #pragma unroll
-                for (int k = 0; k < 7; k++) e1[k] = bsel(0u - (q & 1u), id[k + 1], id[k]);
+                for (int k = 0; k < 7; k++) e1[k] = bsel(0u - (q & 1u), d[k + 1], d[k]);
 #pragma unroll
                 for (int k = 0; k < 5; k++) e2[k] = bsel(0u - ((q >> 1) & 1u), e1[k + 2], e1[k]);
 #pragma unroll
@@ -817,18 +818,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                 for (int j = 0; j < 16; j++) by[j] = (o[j >> 2] >> (8 * (j & 3))) & 255u;
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    id[j] = s_brank[by[j]];
+                    id[j * M16T] = s_brank[by[j]];
                     uint32_t r = JTK_RANK_NONE;
                     if (j + 1 < 16 && j + 1 < len) r = jtk_bp_lookup(bp, (by[j] << 8) | by[(j + 1) & 15]);
-                    rkp[j] = (r == JTK_RANK_NONE) ? RKP_NONE : ((r << 4) | (uint32_t)j);
+                    rk[j * M16T] = (r == JTK_RANK_NONE) ? RKP_NONE : ((r << 4) | (uint32_t)j);
                 }
                 alive = (1u << len) - 1u;
                 st = ST_MERGE;
             }
         }
     }
-    __syncthreads();
-    if (tid <= G && s_tc[tid] && g0 + tid < w.n_tiles) atomicAdd(&w.tile_cnt[g0 + tid], s_tc[tid]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1015,7 +1014,7 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     const unsigned groups = (unsigned)((w.n_tiles + JTK_HARD_GROUP - 1) / JTK_HARD_GROUP);
-    hipLaunchKernelGGL(k_bpe_merge16, dim3(groups), dim3(256), 0, s, w, t);
+    hipLaunchKernelGGL(k_bpe_merge16, dim3(JTK_Q_SHARDS * JTK_M16_WGS_PER_SHARD), dim3(JTK_M16_THREADS), 0, s, w, t);
     hipLaunchKernelGGL((k_bpe_merge<64, 64>), dim3(groups), dim3(64), 0, s, w, t);
 }
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
