@@ -243,7 +243,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
         (rc = b->tok_at.ensure(nt * JTK_TILE * 4)) ||
         (rc = b->tile_cnt.ensure(nt * 4)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
         (rc = b->hard16.ensure(((nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS) * JTK_HARD16_CAP * JTK_Q_SHARDS * 8)) || (rc = b->hard64.ensure(nt * JTK_HARD64_CAP * 4)) ||
-        (rc = b->n_hard.ensure(nt * 4)) ||
+        (rc = b->n_hard.ensure(nt * 12)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
@@ -266,6 +266,8 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.q16_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
     w.hard64 = (uint32_t*)b->hard64.p;
     w.n_hard64 = (uint32_t*)b->n_hard.p;
+    w.n_hard16 = (uint32_t*)b->n_hard.p + nt;
+    w.q16_base = (uint32_t*)b->n_hard.p + 2 * nt;
     w.mid_list = (JtkLongPiece*)b->mid_list.p;
     w.long_list = (JtkLongPiece*)b->long_list.p;
     w.tokens = (int32_t*)b->tokens.p;

@@ -46,19 +46,28 @@ JTK_HD uint64_t jtk_pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << JT
 // Two-choice bucketed cuckoo table: a key lives in one of two buckets of two 8-byte slots each, so a
 // lookup is exactly two independent 16-byte loads -- never a dependent probe chain.  (On the device a
 // wave advances at the pace of its slowest lane, so "usually one probe, sometimes four" costs four.)
-// `bits` = log2(#buckets).
-JTK_HD uint32_t jtk_pair_hash(uint32_t a, uint32_t b, uint32_t bits) {
+// The bucket count `nb` is sized for the table to sit in one XCD's 4 MiB L2 with room to spare (any
+// count, not a power of two: bucket = hash32 * nb >> 32).
+JTK_HD uint32_t jtk_reduce32(uint32_t h, uint32_t nb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(h, nb);
+#else
+    return (uint32_t)(((uint64_t)h * nb) >> 32);
+#endif
+}
+JTK_HD uint32_t jtk_pair_hash(uint32_t a, uint32_t b, uint32_t nb) {
     uint32_t h = a * 0x9E3779B1u + b * 0x85EBCA77u;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
-    return h >> (32 - bits);
+    h ^= h >> 16;
+    return jtk_reduce32(h, nb);
 }
-JTK_HD uint32_t jtk_pair_hash2(uint32_t a, uint32_t b, uint32_t bits) {
+JTK_HD uint32_t jtk_pair_hash2(uint32_t a, uint32_t b, uint32_t nb) {
     uint32_t h = a * 0xC2B2AE3Du + b * 0x27D4EB2Fu + 0x165667B1u;
     h ^= h >> 13;
     h *= 0x9E3779B1u;
     h ^= h >> 16;
-    return h >> (32 - bits);
+    return jtk_reduce32(h, nb);
 }
 
 struct JtkPairBucket {          // 16 bytes: two slots
@@ -66,7 +75,7 @@ struct JtkPairBucket {          // 16 bytes: two slots
 };
 struct JtkPairTable {
     const JtkPairBucket* buckets;
-    uint32_t bits;   // log2(#buckets)
+    uint32_t bits;   // number of buckets (the field keeps its old name)
 };
 
 JTK_HD uint32_t jtk_pair_match(const JtkPairBucket& v, uint64_t key) {
@@ -127,21 +136,21 @@ struct JtkTok8Slot {
 };
 struct JtkTok8Table {
     const JtkTok8Slot* slots;
-    uint32_t bits;
+    uint32_t bits;   // number of slots (the field keeps its old name)
 };
-JTK_HD uint32_t jtk_tok8_hash(uint32_t lo, uint32_t hi, uint32_t len, uint32_t bits) {
+JTK_HD uint32_t jtk_tok8_hash(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) {
     uint32_t h = lo * 0x9E3779B1u + (hi ^ (len << 27)) * 0x85EBCA77u;
     h ^= h >> 16;
     h *= 0x2C1B3C6Du;
     h ^= h >> 13;
-    return h >> (32 - bits);
+    return jtk_reduce32(h, nslots);
 }
-JTK_HD uint32_t jtk_tok8_hash2(uint32_t lo, uint32_t hi, uint32_t len, uint32_t bits) {
+JTK_HD uint32_t jtk_tok8_hash2(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) {
     uint32_t h = (lo ^ (len << 29)) * 0xC2B2AE3Du + hi * 0x27D4EB2Fu + 0x9E3779B1u;
     h ^= h >> 15;
     h *= 0x85EBCA77u;
     h ^= h >> 13;
-    return h >> (32 - bits);
+    return jtk_reduce32(h, nslots);
 }
 
 // ---- Unicode class lookup ----------------------------------------------------------------------------

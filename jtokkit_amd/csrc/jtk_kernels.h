@@ -62,6 +62,9 @@ struct JtkWork {
     int64_t* tile_off;      // exclusive scan of tile_cnt (n_tiles + 1)
     uint64_t* q16;          // [JTK_Q_SHARDS][q16_cap] pieces of 2..16 bytes queued for bytePairMerge: pos | len << 40
     uint32_t* q16_count;    // [JTK_Q_SHARDS]
+    uint32_t* q16_base;     // [n_tiles] where in its shard a tile's entries start ...
+    uint32_t* n_hard16;     // [n_tiles] ... and how many there are (after bpe_merge16 an entry's top bits
+                            //           hold the piece's token counts: c0 << 48 | c1 << 56)
     int64_t q16_cap;        // entries per shard
     uint32_t* hard64;       // [n_tiles][JTK_HARD64_CAP]
     uint32_t* n_hard64;     // [n_tiles]

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __shared__ uint64_t s_pm[TW];
     __shared__ uint32_t s_cnt[TW];
     __shared__ uint32_t s_pre[TW + 1];
-    __shared__ uint64_t s_q16[JTK_HARD16_CAP];   // this tile's pieces for bpe_merge16
+    __shared__ uint32_t s_q16[JTK_HARD16_CAP];   // this tile's pieces for bpe_merge16: offset | len << 12
     __shared__ uint32_t s_n16, s_n64, s_hits, s_qbase;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&s_n16, (uint32_t)__popcll(bal));
             base = (uint32_t)__shfl((int)base, 0);
-            if (q16) s_q16[base + __popcll(bal & lanemask_lt())] = (uint64_t)(B + pr.s) | ((uint64_t)pr.len << 40);
+            if (q16) s_q16[base + __popcll(bal & lanemask_lt())] = entry;
         }
         bal = __ballot(q64);
         if (bal) {
@@ -488,21 +488,29 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         resolve(k0 + 512 + tid, p2);
         resolve(k0 + 768 + tid, p3);
     }
-    // hit count of the tile
+    // hit count of the tile; the tile's slice of its queue shard is claimed with one returning atomic,
+    // issued before the tile's stores so that its latency hides under them
     for (int d = 32; d >= 1; d >>= 1) my_hits += (uint32_t)__shfl_xor((int)my_hits, d);
     if (lane == 0 && my_hits) atomicAdd(&s_hits, my_hits);
     __syncthreads();
-    for (int i = tid; i < T / 4; i += 256)
-        reinterpret_cast<uint4*>(w.tok_at + B)[i] = reinterpret_cast<const uint4*>(s_id)[i];
+    const uint32_t n16 = s_n16;
     if (tid == 0) {
+        const uint32_t qb = n16 ? atomicAdd(&w.q16_count[tile % JTK_Q_SHARDS], n16) : 0u;
         w.tile_cnt[tile] = s_hits;
         w.n_hard64[tile] = s_n64;
-        s_qbase = s_n16 ? atomicAdd(&w.q16_count[tile % JTK_Q_SHARDS], s_n16) : 0u;   // one returning atomic per tile
+        w.n_hard16[tile] = n16;
+        w.q16_base[tile] = qb;
+        s_qbase = qb;
     }
+    for (int i = tid; i < T / 4; i += 256)
+        reinterpret_cast<uint4*>(w.tok_at + B)[i] = reinterpret_cast<const uint4*>(s_id)[i];
     __syncthreads();
     {
         uint64_t* q = w.q16 + (tile % JTK_Q_SHARDS) * w.q16_cap + s_qbase;
-        for (uint32_t i = tid; i < s_n16; i += 256) q[i] = s_q16[i];
+        for (uint32_t i = tid; i < n16; i += 256) {
+            const uint32_t e = s_q16[i];
+            q[i] = (uint64_t)(B + (e & 4095u)) | ((uint64_t)(e >> 12) << 40);
+        }
     }
 }
 
@@ -521,18 +529,23 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     __shared__ uint32_t s_next;
     constexpr int G = JTK_HARD_GROUP;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t g0 = (int64_t)blockIdx.x * G;
     static_assert(SLOTS == 64, "pieces of <= 16 bytes go to k_bpe_merge16");
     const uint32_t* list = w.hard64;
     const uint32_t* cnts = w.n_hard64;
-    constexpr int CAP = (SLOTS == 16) ? JTK_HARD16_CAP : JTK_HARD64_CAP;
+    constexpr int CAP = JTK_HARD64_CAP;
+    const int64_t n_groups = (w.n_tiles + G - 1) / G;
+    // few, persistent workgroups: most groups have nothing queued, and a workgroup launch costs more
+    // than reading G counters
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t g0 = grp * G;
 
     uint32_t pre[G + 1];                       // only ever indexed by unrolled constants
     pre[0] = 0;
 #pragma unroll
     for (int g = 0; g < G; g++) pre[g + 1] = pre[g] + ((g0 + g < w.n_tiles) ? cnts[g0 + g] : 0u);
     const uint32_t total = pre[G];
-    if (total == 0) return;
+    if (total == 0) continue;
+    __syncthreads();
     for (int i = tid; i < 256; i += THREADS) s_brank[i] = t.byte_rank[i];
     if (tid <= G) s_tc[tid] = 0;
     if (tid == 0) s_next = 0;
@@ -634,6 +647,7 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     }
     __syncthreads();
     if (tid <= G && s_tc[tid] && g0 + tid < w.n_tiles) atomicAdd(&w.tile_cnt[g0 + tid], s_tc[tid]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -682,7 +696,7 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
     const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
     const uint32_t count = w.q16_count[shard];
     if ((uint64_t)kq * M16_CHUNK >= count) return;
-    const uint64_t* queue = w.q16 + (int64_t)shard * w.q16_cap;
+    const uint64_t* queue = w.q16 + (int64_t)shard * w.q16_cap;    // entries are read in aligned pairs
 
     for (int i = tid; i < 1024; i += M16T) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += M16T) s_bpranks[i] = t.bp.ranks[i];
@@ -694,8 +708,11 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
     uint32_t* const id = s_id + tid;
     uint32_t* const rk = s_rk + tid;
 
-    // NEED -> TEXT -> EXPAND -> MERGE ... -> EMIT -> NEED.  Every trip each lane issues the loads of its state,
-    // the wave waits once; the two expensive divergent steps (EXPAND, EMIT) run when a batch has gathered.
+    // NEED -> TEXT -> EXPAND -> MERGE ... -> EMIT -> NEED.  Every trip ALL lanes issue the same four 16-byte
+    // loads (addresses chosen by state, a hot dummy line when idle: no branches, so the four loads are in
+    // flight together and the wave waits once); the expensive divergent steps (EXPAND, EMIT) run when a
+    // batch has gathered, and EMIT's stores are issued at the end of a trip so that they drain under the
+    // next trip's ALU work.
     enum { ST_NEED = 0, ST_TEXT = 1, ST_EXPAND = 2, ST_MERGE = 3, ST_EMIT = 4, ST_DONE = 5 };
     constexpr int BATCH = 24;
     int st = ST_NEED;
@@ -703,6 +720,8 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
     int64_t pos = 0;
     int len = 0;
     uint32_t alive = 0;
+    const uint4* const dummy = reinterpret_cast<const uint4*>(pt.buckets);
+    uint64_t* const queue_rw = w.q16 + (int64_t)shard * w.q16_cap;
 
     for (;;) {
         // (1) merging lanes pick their pair: leftmost minimum of rank << 4 | slot (:234-240)
@@ -728,26 +747,7 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
             } else st = ST_EMIT;                                                             // :261
         }
         const uint64_t b_merge = __ballot(merging);
-        // (2) emit finished pieces (:270-273)
-        const uint64_t b_emit = __ballot(st == ST_EMIT);
-        if (b_emit && (__popcll(b_emit) >= BATCH || !b_merge)) {
-            if (st == ST_EMIT) {
-                const int64_t tile = pos / T;
-                const int64_t tile_end = (tile + 1) * (int64_t)T;
-                uint32_t c0 = 0, c1 = 0;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    if ((alive >> j) & 1u) {
-                        w.tok_at[pos + j] = id[j * M16T];
-                        if (pos + j < tile_end) c0++; else c1++;
-                    }
-                }
-                atomicAdd(&w.tile_cnt[tile], c0);
-                if (c1) atomicAdd(&w.tile_cnt[tile + 1], c1);
-                st = ST_NEED;
-            }
-        }
-        // (3) idle lanes take the next queue entries of this workgroup's chunks
+        // (2) idle lanes take the next queue entries of this workgroup's chunks
         const uint64_t want = __ballot(st == ST_NEED);
         if (want) {
             uint32_t base = 0;
@@ -761,34 +761,37 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
         }
         if (!__ballot(st != ST_DONE)) break;
 
-        // (4) all loads of this trip
-        uint64_t entry = 0;
-        uint4 ta = make_uint4(0, 0, 0, 0), tb = make_uint4(0, 0, 0, 0);
-        JtkPairBucket b11, b12, b21, b22;
-        b11.s0lo = b11.s0hi = b11.s1lo = b11.s1hi = 0xFFFFFFFFu;
-        b12 = b11; b21 = b11; b22 = b11;
-        if (st == ST_NEED) entry = queue[qi];
-        else if (st == ST_TEXT) {
-            const int64_t base = pos & ~(int64_t)15;
-            ta = *reinterpret_cast<const uint4*>(w.text + base);
-            if (base + 16 < w.n_bytes) tb = *reinterpret_cast<const uint4*>(w.text + base + 16);
-        } else if (merging) {
-            if (has_nn) { b11 = pt.buckets[jtk_pair_hash(minr, idnn, pt.bits)]; b12 = pt.buckets[jtk_pair_hash2(minr, idnn, pt.bits)]; }
-            if (has_pv) { b21 = pt.buckets[jtk_pair_hash(idpv, minr, pt.bits)]; b22 = pt.buckets[jtk_pair_hash2(idpv, minr, pt.bits)]; }
+        // (3) the trip's loads: four per lane, unconditional
+        const uint4* a0 = dummy; const uint4* a1 = dummy; const uint4* a2 = dummy; const uint4* a3 = dummy;
+        const int64_t tbase = pos & ~(int64_t)15;
+        if (st == ST_NEED) a0 = reinterpret_cast<const uint4*>(queue + (qi & ~1u));
+        if (st == ST_TEXT) {
+            a0 = reinterpret_cast<const uint4*>(w.text + tbase);
+            a1 = (tbase + 16 < w.n_bytes) ? reinterpret_cast<const uint4*>(w.text + tbase + 16) : a0;
         }
+        if (merging) {
+            const uint4* bk = reinterpret_cast<const uint4*>(pt.buckets);
+            if (has_nn) { a0 = bk + jtk_pair_hash(minr, idnn, pt.bits); a1 = bk + jtk_pair_hash2(minr, idnn, pt.bits); }
+            if (has_pv) { a2 = bk + jtk_pair_hash(idpv, minr, pt.bits); a3 = bk + jtk_pair_hash2(idpv, minr, pt.bits); }
+        }
+        const uint4 v0 = *a0, v1 = *a1, v2 = *a2, v3 = *a3;
 
-        // (5) consume
+        // (4) consume
+        bool emit_now = false;
         if (st == ST_NEED) {
+            const uint64_t entry = (qi & 1u) ? (((uint64_t)v0.w << 32) | v0.z) : (((uint64_t)v0.y << 32) | v0.x);
             pos = (int64_t)(entry & 0xFFFFFFFFFFull);
-            len = (int)(entry >> 40);
+            len = (int)((entry >> 40) & 255u);
             st = ST_TEXT;
         } else if (st == ST_TEXT) {
             // park the 32-byte window in the (idle) part slots until the expansion batch runs
-            id[0 * M16T] = ta.x; id[1 * M16T] = ta.y; id[2 * M16T] = ta.z; id[3 * M16T] = ta.w;
-            id[4 * M16T] = tb.x; id[5 * M16T] = tb.y; id[6 * M16T] = tb.z; id[7 * M16T] = tb.w;
+            id[0 * M16T] = v0.x; id[1 * M16T] = v0.y; id[2 * M16T] = v0.z; id[3 * M16T] = v0.w;
+            id[4 * M16T] = v1.x; id[5 * M16T] = v1.y; id[6 * M16T] = v1.z; id[7 * M16T] = v1.w;
             st = ST_EXPAND;
         } else if (merging) {
             const uint64_t k1 = jtk_pair_key(minr, idnn), k2 = jtk_pair_key(idpv, minr);
+            const JtkPairBucket b11{v0.x, v0.y, v0.z, v0.w}, b12{v1.x, v1.y, v1.z, v1.w};
+            const JtkPairBucket b21{v2.x, v2.y, v2.z, v2.w}, b22{v3.x, v3.y, v3.z, v3.w};
             uint32_t r1 = JTK_RANK_NONE, r2 = JTK_RANK_NONE;
             if (has_nn) { const uint32_t x = jtk_pair_match(b11, k1), y = jtk_pair_match(b12, k1); r1 = x != JTK_RANK_NONE ? x : y; }
             if (has_pv) { const uint32_t x = jtk_pair_match(b21, k2), y = jtk_pair_match(b22, k2); r2 = x != JTK_RANK_NONE ? x : y; }
@@ -798,7 +801,7 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
             id[mini * M16T] = minr;
             alive &= ~(1u << nxt);                                                               // :259
         }
-        // (6) expand parked pieces: 16 bytes at `pos` -> single-byte ids and 2-byte-token ranks (:206-221)
+        // (5) expand parked pieces: 16 bytes at `pos` -> single-byte ids and 2-byte-token ranks (:206-221)
         const uint64_t b_exp = __ballot(st == ST_EXPAND);
         if (b_exp && (__popcll(b_exp) >= BATCH || !__ballot(st == ST_MERGE))) {
             if (st == ST_EXPAND) {
@@ -827,7 +830,40 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
                 st = ST_MERGE;
             }
         }
+        // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The
+        // piece's token counts (in its tile / spilling into the next) go back into its queue entry;
+        // k_tile_counts sums them per tile -- no atomics here.
+        const uint64_t b_emit = __ballot(st == ST_EMIT);
+        emit_now = b_emit && (__popcll(b_emit) >= BATCH || !b_merge);
+        if (emit_now) {
+            if (st == ST_EMIT) {
+                const int64_t tile_end = (pos / T + 1) * (int64_t)T;
+                uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if ((alive >> j) & 1u) {
+                        w.tok_at[pos + j] = id[j * M16T];
+                        if (pos + j < tile_end) c0++; else c1++;
+                    }
+                }
+                queue_rw[qi] = (uint64_t)pos | ((uint64_t)len << 40) | ((uint64_t)c0 << 48) | ((uint64_t)c1 << 56);
+                st = ST_NEED;
+            }
+        }
     }
+}
+
+// per tile: add the token counts bpe_merge16 left in the tile's queue entries
+__global__ void __launch_bounds__(256) k_tile_counts(JtkWork w) {
+    const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= w.n_tiles) return;
+    const uint32_t n = w.n_hard16[tile];
+    if (!n) return;
+    const uint64_t* q = w.q16 + (tile % JTK_Q_SHARDS) * w.q16_cap + w.q16_base[tile];
+    uint32_t c0 = 0, c1 = 0;
+    for (uint32_t i = 0; i < n; i++) { const uint64_t e = q[i]; c0 += (uint32_t)(e >> 48) & 255u; c1 += (uint32_t)(e >> 56); }
+    atomicAdd(&w.tile_cnt[tile], c0);
+    if (c1) atomicAdd(&w.tile_cnt[tile + 1], c1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1015,7 +1051,8 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     const unsigned groups = (unsigned)((w.n_tiles + JTK_HARD_GROUP - 1) / JTK_HARD_GROUP);
     hipLaunchKernelGGL(k_bpe_merge16, dim3(JTK_Q_SHARDS * JTK_M16_WGS_PER_SHARD), dim3(JTK_M16_THREADS), 0, s, w, t);
-    hipLaunchKernelGGL((k_bpe_merge<64, 64>), dim3(groups), dim3(64), 0, s, w, t);
+    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 255) / 256)), dim3(256), 0, s, w);
+    hipLaunchKernelGGL((k_bpe_merge<64, 64>), dim3(groups < 1024 ? groups : 1024), dim3(64), 0, s, w, t);
 }
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_merge_long<JTK_MID_CAP>, dim3(2048), dim3(64), 0, s, w, t);

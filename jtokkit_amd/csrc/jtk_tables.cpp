@@ -121,21 +121,22 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
     }
     t.n_pairs = (int64_t)pairs.size();
-    // two-choice cuckoo, two slots per bucket; random-walk insertion
+    // two-choice cuckoo, two slots per bucket; random-walk insertion.  Slot load ~0.72: cl100k's 233k
+    // pairs take 2.6 MB, leaving room in a 4 MiB L2 for the streams that pass through it.
     {
-        uint32_t bits = 8;
-        while ((1ull << bits) * 2 * 9 < pairs.size() * 20 + 64) bits++;      // load factor <= 0.45
-        for (;; bits++) {
-            std::vector<uint64_t> slots((size_t)2 << bits, JTK_PAIR_EMPTY);
+        double load = 0.72;
+        for (;; load *= 0.9) {
+            const uint32_t nb = (uint32_t)((double)pairs.size() / (2.0 * load)) + 16;
+            std::vector<uint64_t> slots((size_t)2 * nb, JTK_PAIR_EMPTY);
             uint32_t rng = 0x12345u;
             bool ok = true;
             for (auto& p : pairs) {
                 uint64_t cur = (p.first << 30) | p.second;
                 bool placed = false;
-                for (int kick = 0; kick < 2000 && !placed; kick++) {
+                for (int kick = 0; kick < 5000 && !placed; kick++) {
                     const uint64_t key = cur >> 30;
                     const uint32_t a = (uint32_t)(key >> JTK_ID_BITS), b = (uint32_t)(key & ((1u << JTK_ID_BITS) - 1));
-                    const uint32_t bk[2] = {jtk_pair_hash(a, b, bits), jtk_pair_hash2(a, b, bits)};
+                    const uint32_t bk[2] = {jtk_pair_hash(a, b, nb), jtk_pair_hash2(a, b, nb)};
                     for (int c = 0; c < 2 && !placed; c++)
                         for (int sidx = 0; sidx < 2 && !placed; sidx++)
                             if (slots[(size_t)bk[c] * 2 + sidx] == JTK_PAIR_EMPTY) { slots[(size_t)bk[c] * 2 + sidx] = cur; placed = true; }
@@ -148,8 +149,8 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
                 if (!placed) { ok = false; break; }
             }
             if (!ok) continue;
-            t.pair_bits = bits;
-            t.pair_buckets.resize((size_t)1 << bits);
+            t.pair_bits = nb;
+            t.pair_buckets.resize(nb);
             for (size_t k = 0; k < t.pair_buckets.size(); k++) {
                 const uint64_t s0 = slots[2 * k], s1 = slots[2 * k + 1];
                 t.pair_buckets[k] = JtkPairBucket{(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32)};
@@ -187,16 +188,16 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
     }
     {
-        uint32_t b8 = 8;
-        while ((1ull << b8) * 4 < shorts.size() * 10 + 64) b8++;           // load factor <= 0.4
-        for (;; b8++) {
-            std::vector<JtkTok8Slot> slots((size_t)1 << b8, JtkTok8Slot{0, 0, 0, 0});
+        double load = 0.45;
+        for (;; load *= 0.9) {
+            const uint32_t ns = (uint32_t)((double)shorts.size() / load) + 16;
+            std::vector<JtkTok8Slot> slots(ns, JtkTok8Slot{0, 0, 0, 0});
             uint32_t rng = 0x9876u;
             bool ok = true;
             for (auto cur : shorts) {
                 bool placed = false;
-                for (int kick = 0; kick < 2000 && !placed; kick++) {
-                    const uint32_t h[2] = {jtk_tok8_hash(cur.lo, cur.hi, cur.len, b8), jtk_tok8_hash2(cur.lo, cur.hi, cur.len, b8)};
+                for (int kick = 0; kick < 5000 && !placed; kick++) {
+                    const uint32_t h[2] = {jtk_tok8_hash(cur.lo, cur.hi, cur.len, ns), jtk_tok8_hash2(cur.lo, cur.hi, cur.len, ns)};
                     for (int c = 0; c < 2 && !placed; c++)
                         if (slots[h[c]].len == 0) { slots[h[c]] = cur; placed = true; }
                     if (!placed) {
@@ -207,7 +208,7 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
                 if (!placed) { ok = false; break; }
             }
             if (!ok) continue;
-            t.tok8_bits = b8;
+            t.tok8_bits = ns;
             t.tok8 = slots;
             break;
         }
