@@ -64,7 +64,7 @@ struct jtk_batch {
     hipStream_t last_stream = nullptr;
     DevBuf in_text, in_off;          // staging for the host-buffer entry point
     DevBuf zeroed;                   // docmask | status | result | list counters
-    DevBuf piecemask, tokmask, blk_pre, tok_at, tile_cnt, tile_off, hard16, hard64, n_hard, mid_list, long_list,
+    DevBuf piecemask, tokmask, blk_pre, tok_at, tile_cnt, tile_off, queues, q_meta, mid_list, long_list,
         tokens, tok_off;
     JtkResult* host_result = nullptr;   // pinned
     JtkWork work{};
@@ -193,7 +193,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     (void)hipSetDevice(b->enc->device);
     (void)hipStreamSynchronize(b->stream);
     DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->tokmask, &b->blk_pre, &b->tok_at,
-                      &b->tile_cnt, &b->tile_off, &b->hard16, &b->hard64, &b->n_hard, &b->mid_list, &b->long_list,
+                      &b->tile_cnt, &b->tile_off, &b->queues, &b->q_meta, &b->mid_list, &b->long_list,
                       &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
     if (b->ev_ok) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
@@ -234,16 +234,17 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
 
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
-    const size_t zero_bytes = mask_bytes + status_bytes + 32 + JTK_Q_SHARDS * 4;
+    const size_t zero_bytes = mask_bytes + status_bytes + 32 + JTK_NBINS * JTK_Q_SHARDS * 4;
     const size_t nt = (size_t)w.n_tiles;
     const size_t n_long_max = (size_t)n_bytes / 65 + 2;
+    const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
     int rc;
     if ((rc = b->zeroed.ensure(zero_bytes)) || (rc = b->piecemask.ensure(mask_bytes)) ||
         (rc = b->tokmask.ensure(mask_bytes)) || (rc = b->blk_pre.ensure((size_t)w.n_words * 2)) ||
         (rc = b->tok_at.ensure(nt * JTK_TILE * 4)) ||
         (rc = b->tile_cnt.ensure(nt * 4)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
-        (rc = b->hard16.ensure(((nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS) * JTK_HARD16_CAP * JTK_Q_SHARDS * 8)) || (rc = b->hard64.ensure(nt * JTK_HARD64_CAP * 4)) ||
-        (rc = b->n_hard.ensure(nt * 12)) ||
+        (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2) * 8)) ||
+        (rc = b->q_meta.ensure(nt * 4 * 2 * JTK_NBINS)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
@@ -261,13 +262,19 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.tok_at = (uint32_t*)b->tok_at.p;
     w.tile_cnt = (uint32_t*)b->tile_cnt.p;
     w.tile_off = (int64_t*)b->tile_off.p;
-    w.q16 = (uint64_t*)b->hard16.p;
-    w.q16_cap = (int64_t)((nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS) * JTK_HARD16_CAP;
-    w.q16_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
-    w.hard64 = (uint32_t*)b->hard64.p;
-    w.n_hard64 = (uint32_t*)b->n_hard.p;
-    w.n_hard16 = (uint32_t*)b->n_hard.p + nt;
-    w.q16_base = (uint32_t*)b->n_hard.p + 2 * nt;
+    {
+        const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2};
+        uint64_t* qp = (uint64_t*)b->queues.p;
+        uint32_t* mp = (uint32_t*)b->q_meta.p;
+        for (int k = 0; k < JTK_NBINS; k++) {
+            w.q[k] = qp;
+            w.q_cap[k] = (int64_t)(tps * caps[k]);
+            qp += tps * caps[k] * JTK_Q_SHARDS;
+            w.q_base[k] = mp; mp += nt;
+            w.q_n[k] = mp; mp += nt;
+        }
+        w.q_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
+    }
     w.mid_list = (JtkLongPiece*)b->mid_list.p;
     w.long_list = (JtkLongPiece*)b->long_list.p;
     w.tokens = (int32_t*)b->tokens.p;

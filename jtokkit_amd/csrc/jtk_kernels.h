@@ -10,12 +10,15 @@
 #define JTK_SPLIT_TILE 4096      // bytes per pretok_split workgroup
 #define JTK_SPLIT_HALO 64
 #define JTK_TILE 2048            // bytes per piece_resolve / pack workgroup; token counts are kept per tile
-#define JTK_HARD16_CAP 1024      // per tile: pieces of 2..16 bytes queued for bytePairMerge (>= JTK_TILE / 2)
-#define JTK_Q_SHARDS 64          // dense merge queues: tile t appends to shard t % 64 (one atomic per tile)
-#define JTK_M16_THREADS 1024     // bpe_merge16 workgroup (one per CU; its LDS holds the parts of 1024 pieces)
-#define JTK_M16_WGS_PER_SHARD 4
-#define JTK_HARD64_CAP 128       // per tile: pieces of 17..64 bytes (>= JTK_TILE / 17)
-#define JTK_HARD_GROUP 8         // tiles whose queues one merge workgroup drains
+// Pieces that need bytePairMerge are queued by length bin; bin k holds pieces of up to JTK_BIN_SLOTS(k) bytes.
+// Queues are dense and sharded: tile t appends its entries to shard t % JTK_Q_SHARDS with one returning
+// atomic per tile and bin.  Entry: pos (40 bits) | len << 40 (10 bits) | tokens in its tile << 50 (set by the merge).
+#define JTK_NBINS 3
+#define JTK_Q_SHARDS 64
+#define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
+#define JTK_BIN_CAP1 (JTK_TILE / 16)   //           17..32 bytes
+#define JTK_BIN_CAP2 (JTK_TILE / 32)   //           33..64 bytes
+#define JTK_M_WGS_PER_SHARD 4
 #define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
 #define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin (= JTK_MAX_PIECE_BYTES)
 #define JTK_MAX_SPECIALS 8
@@ -60,14 +63,11 @@ struct JtkWork {
     uint32_t* tok_at;       // per byte position: id of the token starting there, or JTK_ID_DEAD
     uint32_t* tile_cnt;     // tokens starting in each tile
     int64_t* tile_off;      // exclusive scan of tile_cnt (n_tiles + 1)
-    uint64_t* q16;          // [JTK_Q_SHARDS][q16_cap] pieces of 2..16 bytes queued for bytePairMerge: pos | len << 40
-    uint32_t* q16_count;    // [JTK_Q_SHARDS]
-    uint32_t* q16_base;     // [n_tiles] where in its shard a tile's entries start ...
-    uint32_t* n_hard16;     // [n_tiles] ... and how many there are (after bpe_merge16 an entry's top bits
-                            //           hold the piece's token counts: c0 << 48 | c1 << 56)
-    int64_t q16_cap;        // entries per shard
-    uint32_t* hard64;       // [n_tiles][JTK_HARD64_CAP]
-    uint32_t* n_hard64;     // [n_tiles]
+    uint64_t* q[JTK_NBINS];         // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k
+    int64_t q_cap[JTK_NBINS];       // entries per shard
+    uint32_t* q_count;              // [JTK_NBINS][JTK_Q_SHARDS]
+    uint32_t* q_base[JTK_NBINS];    // [n_tiles] where in its shard a tile's entries of bin k start ...
+    uint32_t* q_n[JTK_NBINS];       // [n_tiles] ... and how many there are
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
     uint32_t* mid_count;

@@ -376,8 +376,10 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __shared__ uint64_t s_pm[TW];
     __shared__ uint32_t s_cnt[TW];
     __shared__ uint32_t s_pre[TW + 1];
-    __shared__ uint32_t s_q16[JTK_HARD16_CAP];   // this tile's pieces for bpe_merge16: offset | len << 12
-    __shared__ uint32_t s_n16, s_n64, s_hits, s_qbase;
+    __shared__ uint32_t s_q0[JTK_BIN_CAP0];      // this tile's pieces for the merge kernels, by bin: offset | len << 12
+    __shared__ uint32_t s_q1[JTK_BIN_CAP1];
+    __shared__ uint32_t s_q2[JTK_BIN_CAP2];
+    __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_hits;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -399,7 +401,8 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         s_cnt[tid] = (uint32_t)__popcll(m);
     }
     for (int i = tid; i < T / 4; i += 256) reinterpret_cast<uint4*>(s_id)[i] = make_uint4(JTK_ID_DEAD, JTK_ID_DEAD, JTK_ID_DEAD, JTK_ID_DEAD);
-    if (tid == 0) { s_n16 = 0; s_n64 = 0; s_hits = 0; }
+    if (tid < JTK_NBINS) s_qn[tid] = 0;
+    if (tid == 0) s_hits = 0;
     if (tid == 64) {
         int64_t pos = -1;                                             // scan ahead for the next piece start
         for (int64_t wd = (B >> 6) + TW; pos < 0 && wd < w.n_words; wd++) {
@@ -421,7 +424,6 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     // one lane per piece, four rounds of table probes in flight per lane
     const int64_t next_after = s_next_after;
     const JtkTok8Slot* t8 = t.tok8.slots;
-    uint32_t* const h64 = w.hard64 + tile * JTK_HARD64_CAP;
     uint32_t my_hits = 0;
     struct Probe { int s, len; uint32_t lo, hi, ax, ay, az, aw, bx, by, bz, bw; };
     auto issue = [&](int k, Probe& pr) {
@@ -443,38 +445,36 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         }
     };
     auto resolve = [&](int k, const Probe& pr) {
-        bool q16 = false, q64 = false;
+        int bin = -1;
         if (pr.s >= 0) {
             const int s = pr.s, len = pr.len;
             if (len <= 8) {
                 uint32_t id = JTK_RANK_NONE;
                 if (pr.aw == (uint32_t)len && pr.ax == pr.lo && pr.ay == pr.hi) id = pr.az;
                 else if (pr.bw == (uint32_t)len && pr.bx == pr.lo && pr.by == pr.hi) id = pr.bz;
-                if (id != JTK_RANK_NONE) { s_id[s] = id; my_hits++; } else q16 = true;
-            } else if (len <= 16) {
-                q16 = true;
-            } else if (len <= 64) {
-                q64 = true;
-            } else {
+                if (id != JTK_RANK_NONE) { s_id[s] = id; my_hits++; } else bin = 0;
+            } else if (len <= 16) bin = 0;
+            else if (len <= 32) bin = 1;
+            else if (len <= 64) bin = 2;
+            else {
                 const int64_t len64 = ((k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B)) - s;
                 if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
                 else w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
             }
         }
         const uint32_t entry = (uint32_t)(pr.s & 4095) | ((uint32_t)pr.len << 12);
-        uint64_t bal = __ballot(q16);
-        if (bal) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_n16, (uint32_t)__popcll(bal));
-            base = (uint32_t)__shfl((int)base, 0);
-            if (q16) s_q16[base + __popcll(bal & lanemask_lt())] = entry;
-        }
-        bal = __ballot(q64);
-        if (bal) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_n64, (uint32_t)__popcll(bal));
-            base = (uint32_t)__shfl((int)base, 0);
-            if (q64) h64[base + __popcll(bal & lanemask_lt())] = entry;
+#pragma unroll
+        for (int q = 0; q < JTK_NBINS; q++) {
+            const uint64_t bal = __ballot(bin == q);
+            if (bal) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_qn[q], (uint32_t)__popcll(bal));
+                base = (uint32_t)__shfl((int)base, 0);
+                if (bin == q) {
+                    uint32_t* dst = q == 0 ? s_q0 : (q == 1 ? s_q1 : s_q2);
+                    dst[base + __popcll(bal & lanemask_lt())] = entry;
+                }
+            }
         }
     };
     for (int k0 = 0; k0 < np; k0 += 4 * 256) {
@@ -493,197 +493,53 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     for (int d = 32; d >= 1; d >>= 1) my_hits += (uint32_t)__shfl_xor((int)my_hits, d);
     if (lane == 0 && my_hits) atomicAdd(&s_hits, my_hits);
     __syncthreads();
-    const uint32_t n16 = s_n16;
-    if (tid == 0) {
-        const uint32_t qb = n16 ? atomicAdd(&w.q16_count[tile % JTK_Q_SHARDS], n16) : 0u;
-        w.tile_cnt[tile] = s_hits;
-        w.n_hard64[tile] = s_n64;
-        w.n_hard16[tile] = n16;
-        w.q16_base[tile] = qb;
-        s_qbase = qb;
+    if (tid < JTK_NBINS) {
+        const uint32_t nq = s_qn[tid];
+        const uint32_t qb = nq ? atomicAdd(&w.q_count[tid * JTK_Q_SHARDS + tile % JTK_Q_SHARDS], nq) : 0u;
+        w.q_n[tid][tile] = nq;
+        w.q_base[tid][tile] = qb;
+        s_qbase[tid] = qb;
     }
+    if (tid == 0) w.tile_cnt[tile] = s_hits;
     for (int i = tid; i < T / 4; i += 256)
         reinterpret_cast<uint4*>(w.tok_at + B)[i] = reinterpret_cast<const uint4*>(s_id)[i];
     __syncthreads();
-    {
-        uint64_t* q = w.q16 + (tile % JTK_Q_SHARDS) * w.q16_cap + s_qbase;
-        for (uint32_t i = tid; i < n16; i += 256) {
-            const uint32_t e = s_q16[i];
-            q[i] = (uint64_t)(B + (e & 4095u)) | ((uint64_t)(e >> 12) << 40);
+#pragma unroll
+    for (int q = 0; q < JTK_NBINS; q++) {
+        const uint32_t* src = q == 0 ? s_q0 : (q == 1 ? s_q1 : s_q2);
+        uint64_t* dst = w.q[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + s_qbase[q];
+        const uint32_t nq = s_qn[q];
+        for (uint32_t i = tid; i < nq; i += 256) {
+            const uint32_t e = src[i];
+            dst[i] = (uint64_t)(B + (e & 4095u)) | ((uint64_t)(e >> 12) << 40);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// bpe_merge: bytePairMerge of the queued pieces, ONE LANE PER PIECE, drained densely: a workgroup takes
-// the queues of JTK_HARD_GROUP consecutive tiles so that (almost) every lane has a piece and many
-// dependent lookup chains are in flight per CU.  Parts' ids and pair ranks live in LDS, laid out
-// [slot][lane] so that any per-lane slot index is bank-conflict free.
-// ---------------------------------------------------------------------------------------------------
-template <int SLOTS, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint32_t s_ids[SLOTS * THREADS];
-    __shared__ uint32_t s_rk[SLOTS * THREADS];
-    __shared__ uint32_t s_brank[256];
-    __shared__ uint32_t s_tc[JTK_HARD_GROUP + 1];
-    __shared__ uint32_t s_next;
-    constexpr int G = JTK_HARD_GROUP;
-    const int tid = threadIdx.x, lane = tid & 63;
-    static_assert(SLOTS == 64, "pieces of <= 16 bytes go to k_bpe_merge16");
-    const uint32_t* list = w.hard64;
-    const uint32_t* cnts = w.n_hard64;
-    constexpr int CAP = JTK_HARD64_CAP;
-    const int64_t n_groups = (w.n_tiles + G - 1) / G;
-    // few, persistent workgroups: most groups have nothing queued, and a workgroup launch costs more
-    // than reading G counters
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const int64_t g0 = grp * G;
-
-    uint32_t pre[G + 1];                       // only ever indexed by unrolled constants
-    pre[0] = 0;
-#pragma unroll
-    for (int g = 0; g < G; g++) pre[g + 1] = pre[g] + ((g0 + g < w.n_tiles) ? cnts[g0 + g] : 0u);
-    const uint32_t total = pre[G];
-    if (total == 0) continue;
-    __syncthreads();
-    for (int i = tid; i < 256; i += THREADS) s_brank[i] = t.byte_rank[i];
-    if (tid <= G) s_tc[tid] = 0;
-    if (tid == 0) s_next = 0;
-    __syncthreads();
-
-    uint32_t* const ids = s_ids + tid;
-    uint32_t* const rk = s_rk + tid;
-    const JtkPairTable pt = t.pairs;
-
-    // Every lane is a small state machine: take the next queued piece, set up its parts, then one merge
-    // per loop trip until no pair is left; lanes re-arm independently, so the wave stays full while the
-    // queue lasts and many lookup chains are in flight.
-    bool active = false, exhausted = false;
-    int64_t pos = 0;
-    int g = 0;
-    uint64_t alive = 0;
-    for (;;) {
-        const uint64_t want = __ballot(!active && !exhausted);
-        if (want) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_next, (uint32_t)__popcll(want));
-            base = (uint32_t)__shfl((int)base, 0);
-            if (!active && !exhausted) {
-                const uint32_t i = base + (uint32_t)__popcll(want & lanemask_lt());
-                if (i >= total) exhausted = true;
-                else {
-                    g = 0;
-                    uint32_t gbase = 0;
-#pragma unroll
-                    for (int q = 1; q < G; q++) if (i >= pre[q]) { g = q; gbase = pre[q]; }
-                    const uint32_t entry = list[(g0 + g) * CAP + (i - gbase)];
-                    pos = (g0 + g) * T + (entry & 4095u);
-                    const int len = (int)(entry >> 12);
-                    // stage the piece's bytes (aligned dwords) in the rk slots, then expand to ids / pair ranks
-                    const uint32_t off = (uint32_t)(pos & 3);
-                    const uint32_t* src = reinterpret_cast<const uint32_t*>(w.text + (pos - off));
-                    constexpr int NDW = SLOTS / 4 + 1;
-#pragma unroll
-                    for (int k = 0; k < NDW; k++)
-                        if ((int)(k * 4) < (int)off + len) rk[k * THREADS] = src[k];
-                    const uint8_t* rkb = reinterpret_cast<const uint8_t*>(rk);
-                    uint32_t prev = rkb[(off >> 2) * THREADS * 4 + (off & 3)];
-                    for (int j = 0; j + 1 < len; j++) {
-                        const uint32_t o = off + j + 1;
-                        const uint32_t cur = rkb[(o >> 2) * THREADS * 4 + (o & 3)];
-                        ids[j * THREADS] = (prev << 8) | cur;           // byte pair, expanded below
-                        prev = cur;
-                    }
-                    ids[(len - 1) * THREADS] = prev << 8;
-                    for (int j = 0; j < len; j++) {
-                        const uint32_t bp = ids[j * THREADS];
-                        rk[j * THREADS] = (j + 1 < len) ? t.bp_rank[bp] : JTK_RANK_NONE;   // :216-221
-                        ids[j * THREADS] = s_brank[bp >> 8];
-                    }
-                    alive = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);
-                    active = true;
-                }
-            }
-        }
-        if (!__ballot(active)) break;
-        if (active) {
-            uint32_t minr = JTK_RANK_NONE;
-            int mini = 0;
-            for (uint64_t m = alive; m;) {                                                   // :234-240
-                const int j = jtk_ctz64(m);
-                m &= m - 1;
-                const uint32_t r = rk[j * THREADS];
-                if (r < minr) { minr = r; mini = j; }
-            }
-            if (minr != JTK_RANK_NONE) {                                                     // :247
-                const uint64_t above = alive & ~((2ull << mini) - 1ull);
-                const int nxt = jtk_ctz64(above);
-                const uint64_t above2 = above & (above - 1);
-                const uint64_t below = alive & ((1ull << mini) - 1ull);
-                const int nn = above2 ? jtk_ctz64(above2) : 0;
-                const int pv = below ? 63 - jtk_clz64(below) : 0;
-                uint32_t r1, r2;
-                jtk_pair_lookup2(pt, minr, above2 ? ids[nn * THREADS] : 0u, above2 != 0, below ? ids[pv * THREADS] : 0u,
-                                 minr, below != 0, r1, r2);                                  // :254-257
-                if (below) rk[pv * THREADS] = r2;
-                ids[mini * THREADS] = minr;
-                rk[mini * THREADS] = r1;
-                alive &= ~(1ull << nxt);                                                     // :259
-            } else {                                                                         // :261
-                // tokens go to the byte positions their parts start at; count them per tile
-                const int64_t tile_end = (g0 + g + 1) * (int64_t)T;
-                uint32_t c0 = 0, c1 = 0;
-                for (uint64_t m = alive; m;) {
-                    const int j = jtk_ctz64(m);
-                    m &= m - 1;
-                    w.tok_at[pos + j] = ids[j * THREADS];
-                    if (pos + j < tile_end) c0++; else c1++;
-                }
-                atomicAdd(&s_tc[g], c0);
-                if (c1) atomicAdd(&s_tc[g + 1], c1);
-                active = false;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid <= G && s_tc[tid] && g0 + tid < w.n_tiles) atomicAdd(&w.tile_cnt[g0 + tid], s_tc[tid]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// bpe_merge16: the common case (pieces of 2..16 bytes that are not single tokens), built around what
-// bounds it -- dependent table lookups.  Per lane a small state machine: NEED -> (queue entry) ->
-// TEXT -> (16 text bytes) -> MERGE ... -> emit.  Every trip of the loop each lane issues the loads of
-// its current state, then the wave waits ONCE, so a piece costs (2 + merges) round trips and a wave
-// keeps 64 independent chains in flight.  The parts of a piece (ids and pair ranks) live in 32
-// REGISTERS per lane (all indices unrolled), which leaves LDS to the tables: the byte -> rank table and
-// the complete 2-byte-token table (bitmap + ranks) are staged in LDS, so setting a piece up needs no
-// global lookups; only the (left id, right id) pair table is read from L2.
-// Leftmost-minimum (GptBytePairEncoding.java:236): min over key = rank << 4 | slot.
+// bpe_merge: bytePairMerge (GptBytePairEncoding.java:200-275) of the queued pieces, ONE LANE PER PIECE,
+// built around what bounds it -- dependent table lookups.  Each lane is a small state machine:
+//     NEED -> (queue entry) -> TEXT -> (the piece's bytes) -> EXPAND -> MERGE ... -> EMIT -> NEED
+// Every trip of the loop ALL lanes issue the same four 16-byte loads (addresses chosen by state, a hot
+// dummy line when idle: no branches, so the loads are in flight together and the wave waits once); a
+// piece costs (2..3 + merges) round trips and every wave keeps 64 independent chains in flight.  Lanes
+// draw from a dense, sharded queue, so the wave stays full while the queue lasts.
+// The parts of a piece (ids, pair ranks) live in LDS laid out [slot][lane] -- conflict-free for any
+// per-lane slot index -- and so do the byte -> rank table and the complete 2-byte-token table (bitmap +
+// ranks): setting a piece up needs no global lookups; only the (left id, right id) pair table is read
+// from L2.  The two expensive divergent steps (EXPAND, EMIT) run when a batch of lanes has gathered.
+// Leftmost-minimum (:236): min over key = rank << 9 | slot.
+// One instantiation per length bin: <16 slots, 1024 lanes>, <32, 512>, <64, 256> -- 128 KiB of parts each.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t RKP_NONE = 0xFFFFFFFFu;
+constexpr int M_CHUNK = 2048;                  // queue entries a workgroup takes at a time
 
-// a[i] for a register-resident array: a 4-level tree of bitwise selects (v_bfi), written with masks so
-// that the compiler does not turn it back into an indexed (scratch) access.
 __device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t x1, uint32_t x0) { return (x1 & m) | (x0 & ~m); }
-__device__ __forceinline__ uint32_t sel16(const uint32_t (&a)[16], uint32_t i) {
-    const uint32_t m0 = 0u - (i & 1u), m1 = 0u - ((i >> 1) & 1u), m2 = 0u - ((i >> 2) & 1u), m3 = 0u - ((i >> 3) & 1u);
-    uint32_t t8[8], t4[4], t2[2];
-#pragma unroll
-    for (int k = 0; k < 8; k++) t8[k] = bsel(m0, a[2 * k + 1], a[2 * k]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) t4[k] = bsel(m1, t8[2 * k + 1], t8[2 * k]);
-#pragma unroll
-    for (int k = 0; k < 2; k++) t2[k] = bsel(m2, t4[2 * k + 1], t4[2 * k]);
-    return bsel(m3, t2[1], t2[0]);
-}
 
-constexpr int M16T = JTK_M16_THREADS;
-constexpr int M16_CHUNK = 2048;                // queue entries a workgroup takes at a time
-
-__global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint32_t s_id[16 * M16T];       // parts of the pieces in flight, [slot][lane]: conflict free
-    __shared__ uint32_t s_rk[16 * M16T];       //   for any per-lane slot index
+template <int SLOTS, int THREADS, int BIN>
+__global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
+    __shared__ uint32_t s_id[SLOTS * THREADS];
+    __shared__ uint32_t s_rk[SLOTS * THREADS];
     __shared__ uint64_t s_bpbits[1024];
     __shared__ uint32_t s_bpranks[JTK_BP_MAX];
     __shared__ uint16_t s_bpcum[1024];
@@ -694,13 +550,13 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
     // dense queue shard `shard`; this workgroup takes chunks kq, kq + K, kq + 2K, ... of it
     const int shard = blockIdx.x % JTK_Q_SHARDS;
     const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
-    const uint32_t count = w.q16_count[shard];
-    if ((uint64_t)kq * M16_CHUNK >= count) return;
-    const uint64_t* queue = w.q16 + (int64_t)shard * w.q16_cap;    // entries are read in aligned pairs
+    const uint32_t count = w.q_count[BIN * JTK_Q_SHARDS + shard];
+    if ((uint64_t)kq * M_CHUNK >= count) return;
+    uint64_t* const queue = w.q[BIN] + (int64_t)shard * w.q_cap[BIN];     // entries are read in aligned pairs
 
-    for (int i = tid; i < 1024; i += M16T) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
-    for (int i = tid; i < JTK_BP_MAX; i += M16T) s_bpranks[i] = t.bp.ranks[i];
-    if (tid < 256) s_brank[tid] = t.byte_rank[tid];
+    for (int i = tid; i < 1024; i += THREADS) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
+    for (int i = tid; i < JTK_BP_MAX; i += THREADS) s_bpranks[i] = t.bp.ranks[i];
+    for (int i = tid; i < 256; i += THREADS) s_brank[i] = t.byte_rank[i];
     if (tid == 0) s_next = 0;
     __syncthreads();
     const JtkBpLds bp{s_bpbits, s_bpcum, s_bpranks};
@@ -708,42 +564,40 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
     uint32_t* const id = s_id + tid;
     uint32_t* const rk = s_rk + tid;
 
-    // NEED -> TEXT -> EXPAND -> MERGE ... -> EMIT -> NEED.  Every trip ALL lanes issue the same four 16-byte
-    // loads (addresses chosen by state, a hot dummy line when idle: no branches, so the four loads are in
-    // flight together and the wave waits once); the expensive divergent steps (EXPAND, EMIT) run when a
-    // batch has gathered, and EMIT's stores are issued at the end of a trip so that they drain under the
-    // next trip's ALU work.
     enum { ST_NEED = 0, ST_TEXT = 1, ST_EXPAND = 2, ST_MERGE = 3, ST_EMIT = 4, ST_DONE = 5 };
     constexpr int BATCH = 24;
     int st = ST_NEED;
     uint32_t qi = 0;
     int64_t pos = 0;
-    int len = 0;
-    uint32_t alive = 0;
+    int len = 0, tpart = 0;
+    uint64_t alive = 0;
     const uint4* const dummy = reinterpret_cast<const uint4*>(pt.buckets);
-    uint64_t* const queue_rw = w.q16 + (int64_t)shard * w.q16_cap;
 
     for (;;) {
-        // (1) merging lanes pick their pair: leftmost minimum of rank << 4 | slot (:234-240)
+        // (1) merging lanes pick their pair: leftmost minimum of rank << 9 | slot (:234-240)
         uint32_t minr = 0, mini = 0, nxt = 0, nn = 0, pv = 0, idnn = 0, idpv = 0;
         bool has_nn = false, has_pv = false, merging = false;
         if (st == ST_MERGE) {
             uint32_t m = RKP_NONE;
+            if (SLOTS <= 16) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) m = min(m, rk[j * M16T]);
+                for (int j = 0; j < SLOTS; j++) m = min(m, rk[j * THREADS]);
+            } else {
+                for (int j = 0; j < len; j++) m = min(m, rk[j * THREADS]);
+            }
             if (m != RKP_NONE) {                                                             // :247
                 merging = true;
-                minr = m >> 4; mini = m & 15u;
-                const uint32_t above = alive & ~((2u << mini) - 1u);
-                nxt = (uint32_t)__ffs((int)above) - 1u;
-                const uint32_t above2 = above & (above - 1u);
+                minr = m >> 9; mini = m & 511u;
+                const uint64_t above = alive & ~((2ull << mini) - 1ull);
+                nxt = (uint32_t)jtk_ctz64(above);
+                const uint64_t above2 = above & (above - 1ull);
                 has_nn = above2 != 0;
-                nn = has_nn ? (uint32_t)__ffs((int)above2) - 1u : 0u;
-                const uint32_t below = alive & ((1u << mini) - 1u);
+                nn = has_nn ? (uint32_t)jtk_ctz64(above2) : 0u;
+                const uint64_t below = alive & ((1ull << mini) - 1ull);
                 has_pv = below != 0;
-                pv = has_pv ? 31u - (uint32_t)__clz((int)below) : 0u;
-                idnn = id[nn * M16T];
-                idpv = id[pv * M16T];
+                pv = has_pv ? 63u - (uint32_t)jtk_clz64(below) : 0u;
+                idnn = id[nn * THREADS];
+                idpv = id[pv * THREADS];
             } else st = ST_EMIT;                                                             // :261
         }
         const uint64_t b_merge = __ballot(merging);
@@ -755,7 +609,7 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
             base = (uint32_t)__shfl((int)base, 0);
             if (st == ST_NEED) {
                 const uint32_t seq = base + (uint32_t)__popcll(want & lanemask_lt());
-                const uint64_t idx = (uint64_t)(kq + (seq / M16_CHUNK) * K) * M16_CHUNK + (seq % M16_CHUNK);
+                const uint64_t idx = (uint64_t)(kq + (seq / M_CHUNK) * K) * M_CHUNK + (seq % M_CHUNK);
                 if (idx >= count) st = ST_DONE; else qi = (uint32_t)idx;
             }
         }
@@ -763,11 +617,14 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
 
         // (3) the trip's loads: four per lane, unconditional
         const uint4* a0 = dummy; const uint4* a1 = dummy; const uint4* a2 = dummy; const uint4* a3 = dummy;
-        const int64_t tbase = pos & ~(int64_t)15;
+        const int64_t tbase = (pos & ~(int64_t)15) + 64 * (int64_t)tpart;
         if (st == ST_NEED) a0 = reinterpret_cast<const uint4*>(queue + (qi & ~1u));
         if (st == ST_TEXT) {
-            a0 = reinterpret_cast<const uint4*>(w.text + tbase);
-            a1 = (tbase + 16 < w.n_bytes) ? reinterpret_cast<const uint4*>(w.text + tbase + 16) : a0;
+            const uint4* tx = reinterpret_cast<const uint4*>(w.text + tbase);
+            a0 = tx;                                                  // reads stay inside the text buffer
+            a1 = (tbase + 16 < w.n_bytes) ? tx + 1 : tx;
+            a2 = (tbase + 32 < w.n_bytes) ? tx + 2 : tx;
+            a3 = (tbase + 48 < w.n_bytes) ? tx + 3 : tx;
         }
         if (merging) {
             const uint4* bk = reinterpret_cast<const uint4*>(pt.buckets);
@@ -777,17 +634,27 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
         const uint4 v0 = *a0, v1 = *a1, v2 = *a2, v3 = *a3;
 
         // (4) consume
-        bool emit_now = false;
         if (st == ST_NEED) {
             const uint64_t entry = (qi & 1u) ? (((uint64_t)v0.w << 32) | v0.z) : (((uint64_t)v0.y << 32) | v0.x);
             pos = (int64_t)(entry & 0xFFFFFFFFFFull);
-            len = (int)((entry >> 40) & 255u);
+            len = (int)((entry >> 40) & 1023u);
+            tpart = 0;
             st = ST_TEXT;
         } else if (st == ST_TEXT) {
-            // park the 32-byte window in the (idle) part slots until the expansion batch runs
-            id[0 * M16T] = v0.x; id[1 * M16T] = v0.y; id[2 * M16T] = v0.z; id[3 * M16T] = v0.w;
-            id[4 * M16T] = v1.x; id[5 * M16T] = v1.y; id[6 * M16T] = v1.z; id[7 * M16T] = v1.w;
-            st = ST_EXPAND;
+            // park this 64-byte slab of the window in the (idle) rank slots until the expansion batch runs
+            uint32_t* park = rk + 16 * tpart * THREADS;
+            if (16 * tpart + 15 < SLOTS || SLOTS >= 32) {
+                park[0 * THREADS] = v0.x; park[1 * THREADS] = v0.y; park[2 * THREADS] = v0.z; park[3 * THREADS] = v0.w;
+                park[4 * THREADS] = v1.x; park[5 * THREADS] = v1.y; park[6 * THREADS] = v1.z; park[7 * THREADS] = v1.w;
+            }
+            if (SLOTS >= 32 && 16 * tpart + 8 < SLOTS) {
+                park[8 * THREADS] = v2.x; park[9 * THREADS] = v2.y; park[10 * THREADS] = v2.z; park[11 * THREADS] = v2.w;
+            }
+            if (SLOTS >= 32 && 16 * tpart + 12 < SLOTS) {
+                park[12 * THREADS] = v3.x; park[13 * THREADS] = v3.y; park[14 * THREADS] = v3.z; park[15 * THREADS] = v3.w;
+            }
+            tpart++;
+            if ((int64_t)(pos & 15) + len <= 64 * (int64_t)tpart) st = ST_EXPAND;
         } else if (merging) {
             const uint64_t k1 = jtk_pair_key(minr, idnn), k2 = jtk_pair_key(idpv, minr);
             const JtkPairBucket b11{v0.x, v0.y, v0.z, v0.w}, b12{v1.x, v1.y, v1.z, v1.w};
@@ -795,75 +662,105 @@ __global__ void __launch_bounds__(M16T) k_bpe_merge16(JtkWork w, JtkDeviceTables
             uint32_t r1 = JTK_RANK_NONE, r2 = JTK_RANK_NONE;
             if (has_nn) { const uint32_t x = jtk_pair_match(b11, k1), y = jtk_pair_match(b12, k1); r1 = x != JTK_RANK_NONE ? x : y; }
             if (has_pv) { const uint32_t x = jtk_pair_match(b21, k2), y = jtk_pair_match(b22, k2); r2 = x != JTK_RANK_NONE ? x : y; }
-            if (has_pv) rk[pv * M16T] = (r2 == JTK_RANK_NONE) ? RKP_NONE : ((r2 << 4) | pv);     // :255-257
-            rk[mini * M16T] = (r1 == JTK_RANK_NONE) ? RKP_NONE : ((r1 << 4) | mini);             // :254
-            rk[nxt * M16T] = RKP_NONE;
-            id[mini * M16T] = minr;
-            alive &= ~(1u << nxt);                                                               // :259
+            if (has_pv) rk[pv * THREADS] = (r2 == JTK_RANK_NONE) ? RKP_NONE : ((r2 << 9) | pv);     // :255-257
+            rk[mini * THREADS] = (r1 == JTK_RANK_NONE) ? RKP_NONE : ((r1 << 9) | mini);             // :254
+            rk[nxt * THREADS] = RKP_NONE;
+            id[mini * THREADS] = minr;
+            alive &= ~(1ull << nxt);                                                                // :259
         }
-        // (5) expand parked pieces: 16 bytes at `pos` -> single-byte ids and 2-byte-token ranks (:206-221)
+        // (5) expand parked pieces: bytes at `pos` -> single-byte ids and 2-byte-token ranks (:206-221)
         const uint64_t b_exp = __ballot(st == ST_EXPAND);
         if (b_exp && (__popcll(b_exp) >= BATCH || !__ballot(st == ST_MERGE))) {
             if (st == ST_EXPAND) {
-                uint32_t d[8];
+                const uint32_t off = (uint32_t)(pos & 15);
+                const uint8_t* rkb = reinterpret_cast<const uint8_t*>(rk);
+                if (SLOTS <= 16) {
+                    // fixed 16 bytes, everything unrolled
+                    uint32_t d[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) d[k] = id[k * M16T];
-                const uint32_t off = (uint32_t)(pos & 15), q = off >> 2, sh = off & 3u;
-                uint32_t e1[7], e2[5], o[4];
+                    for (int k = 0; k < 8; k++) d[k] = rk[k * THREADS];
+                    const uint32_t q = off >> 2, sh = off & 3u;
+                    uint32_t e1[7], e2[5], o[4];
 #pragma unroll
-                for (int k = 0; k < 7; k++) e1[k] = bsel(0u - (q & 1u), d[k + 1], d[k]);
+                    for (int k = 0; k < 7; k++) e1[k] = bsel(0u - (q & 1u), d[k + 1], d[k]);
 #pragma unroll
-                for (int k = 0; k < 5; k++) e2[k] = bsel(0u - ((q >> 1) & 1u), e1[k + 2], e1[k]);
+                    for (int k = 0; k < 5; k++) e2[k] = bsel(0u - ((q >> 1) & 1u), e1[k + 2], e1[k]);
 #pragma unroll
-                for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_alignbyte(e2[k + 1], e2[k], sh);
-                uint32_t by[16];
+                    for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_alignbyte(e2[k + 1], e2[k], sh);
+                    uint32_t by[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) by[j] = (o[j >> 2] >> (8 * (j & 3))) & 255u;
+                    for (int j = 0; j < 16; j++) by[j] = (o[j >> 2] >> (8 * (j & 3))) & 255u;
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    id[j * M16T] = s_brank[by[j]];
-                    uint32_t r = JTK_RANK_NONE;
-                    if (j + 1 < 16 && j + 1 < len) r = jtk_bp_lookup(bp, (by[j] << 8) | by[(j + 1) & 15]);
-                    rk[j * M16T] = (r == JTK_RANK_NONE) ? RKP_NONE : ((r << 4) | (uint32_t)j);
+                    for (int j = 0; j < 16; j++) {
+                        id[j * THREADS] = s_brank[by[j]];
+                        uint32_t r = JTK_RANK_NONE;
+                        if (j + 1 < 16 && j + 1 < len) r = jtk_bp_lookup(bp, (by[j] << 8) | by[(j + 1) & 15]);
+                        rk[j * THREADS] = (r == JTK_RANK_NONE) ? RKP_NONE : ((r << 9) | (uint32_t)j);
+                    }
+                } else {
+                    uint32_t prev = rkb[(off >> 2) * THREADS * 4 + (off & 3)];
+                    for (int j = 0; j + 1 < len; j++) {
+                        const uint32_t o = off + j + 1;
+                        const uint32_t cur = rkb[(o >> 2) * THREADS * 4 + (o & 3)];
+                        id[j * THREADS] = (prev << 8) | cur;               // byte pair, expanded below
+                        prev = cur;
+                    }
+                    id[(len - 1) * THREADS] = prev << 8;
+                    for (int j = 0; j < len; j++) {
+                        const uint32_t bpi = id[j * THREADS];
+                        const uint32_t r = (j + 1 < len) ? jtk_bp_lookup(bp, bpi) : JTK_RANK_NONE;
+                        rk[j * THREADS] = (r == JTK_RANK_NONE) ? RKP_NONE : ((r << 9) | (uint32_t)j);
+                        id[j * THREADS] = s_brank[bpi >> 8];
+                    }
                 }
-                alive = (1u << len) - 1u;
+                alive = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);
                 st = ST_MERGE;
             }
         }
-        // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The
-        // piece's token counts (in its tile / spilling into the next) go back into its queue entry;
-        // k_tile_counts sums them per tile -- no atomics here.
+        // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The number
+        // of tokens that start in the piece's own tile goes back into its queue entry (k_tile_counts sums them
+        // per tile, no atomics here); tokens spilling into the next tile are rare and counted atomically.
         const uint64_t b_emit = __ballot(st == ST_EMIT);
-        emit_now = b_emit && (__popcll(b_emit) >= BATCH || !b_merge);
-        if (emit_now) {
+        if (b_emit && (__popcll(b_emit) >= BATCH || !b_merge)) {
             if (st == ST_EMIT) {
                 const int64_t tile_end = (pos / T + 1) * (int64_t)T;
                 uint32_t c0 = 0, c1 = 0;
+                if (SLOTS <= 16) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    if ((alive >> j) & 1u) {
-                        w.tok_at[pos + j] = id[j * M16T];
+                    for (int j = 0; j < SLOTS; j++) {
+                        if ((alive >> j) & 1ull) {
+                            w.tok_at[pos + j] = id[j * THREADS];
+                            if (pos + j < tile_end) c0++; else c1++;
+                        }
+                    }
+                } else {
+                    for (uint64_t m = alive; m;) {
+                        const int j = jtk_ctz64(m);
+                        m &= m - 1;
+                        w.tok_at[pos + j] = id[j * THREADS];
                         if (pos + j < tile_end) c0++; else c1++;
                     }
                 }
-                queue_rw[qi] = (uint64_t)pos | ((uint64_t)len << 40) | ((uint64_t)c0 << 48) | ((uint64_t)c1 << 56);
+                queue[qi] = (uint64_t)pos | ((uint64_t)len << 40) | ((uint64_t)c0 << 50);
+                if (c1) atomicAdd(&w.tile_cnt[pos / T + 1], c1);
                 st = ST_NEED;
             }
         }
     }
 }
 
-// per tile: add the token counts bpe_merge16 left in the tile's queue entries
+// per tile: add the token counts the merge kernels left in the tile's queue entries
 __global__ void __launch_bounds__(256) k_tile_counts(JtkWork w) {
     const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= w.n_tiles) return;
-    const uint32_t n = w.n_hard16[tile];
-    if (!n) return;
-    const uint64_t* q = w.q16 + (tile % JTK_Q_SHARDS) * w.q16_cap + w.q16_base[tile];
-    uint32_t c0 = 0, c1 = 0;
-    for (uint32_t i = 0; i < n; i++) { const uint64_t e = q[i]; c0 += (uint32_t)(e >> 48) & 255u; c1 += (uint32_t)(e >> 56); }
-    atomicAdd(&w.tile_cnt[tile], c0);
-    if (c1) atomicAdd(&w.tile_cnt[tile + 1], c1);
+    uint32_t c0 = 0;
+#pragma unroll
+    for (int k = 0; k < JTK_NBINS; k++) {
+        const uint32_t n = w.q_n[k][tile];
+        const uint64_t* q = w.q[k] + (tile % JTK_Q_SHARDS) * w.q_cap[k] + w.q_base[k][tile];
+        for (uint32_t i = 0; i < n; i++) c0 += (uint32_t)(q[i] >> 50) & 1023u;
+    }
+    if (c0) atomicAdd(&w.tile_cnt[tile], c0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1049,10 +946,11 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
     hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    const unsigned groups = (unsigned)((w.n_tiles + JTK_HARD_GROUP - 1) / JTK_HARD_GROUP);
-    hipLaunchKernelGGL(k_bpe_merge16, dim3(JTK_Q_SHARDS * JTK_M16_WGS_PER_SHARD), dim3(JTK_M16_THREADS), 0, s, w, t);
+    const dim3 grid(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD);
+    hipLaunchKernelGGL((k_bpe_merge<16, 1024, 0>), grid, dim3(1024), 0, s, w, t);
+    hipLaunchKernelGGL((k_bpe_merge<32, 512, 1>), grid, dim3(512), 0, s, w, t);
+    hipLaunchKernelGGL((k_bpe_merge<64, 256, 2>), grid, dim3(256), 0, s, w, t);
     hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 255) / 256)), dim3(256), 0, s, w);
-    hipLaunchKernelGGL((k_bpe_merge<64, 64>), dim3(groups < 1024 ? groups : 1024), dim3(64), 0, s, w, t);
 }
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_merge_long<JTK_MID_CAP>, dim3(2048), dim3(64), 0, s, w, t);
