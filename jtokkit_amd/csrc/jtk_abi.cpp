@@ -236,14 +236,14 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
     const size_t zero_bytes = mask_bytes + status_bytes + 32 + JTK_NBINS * JTK_Q_SHARDS * 4;
     const size_t nt = (size_t)w.n_tiles;
-    const size_t n_long_max = (size_t)n_bytes / 65 + 2;
+    const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
     int rc;
     if ((rc = b->zeroed.ensure(zero_bytes)) || (rc = b->piecemask.ensure(mask_bytes)) ||
         (rc = b->tokmask.ensure(mask_bytes)) || (rc = b->blk_pre.ensure((size_t)w.n_words * 2)) ||
         (rc = b->tok_at.ensure(nt * JTK_TILE * 4)) ||
         (rc = b->tile_cnt.ensure(nt * 4)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
-        (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2) * 8)) ||
+        (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 8)) ||
         (rc = b->q_meta.ensure(nt * 4 * 2 * JTK_NBINS)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
@@ -263,7 +263,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.tile_cnt = (uint32_t*)b->tile_cnt.p;
     w.tile_off = (int64_t*)b->tile_off.p;
     {
-        const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2};
+        const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4};
         uint64_t* qp = (uint64_t*)b->queues.p;
         uint32_t* mp = (uint32_t*)b->q_meta.p;
         for (int k = 0; k < JTK_NBINS; k++) {

@@ -13,11 +13,14 @@
 // Pieces that need bytePairMerge are queued by length bin; bin k holds pieces of up to JTK_BIN_SLOTS(k) bytes.
 // Queues are dense and sharded: tile t appends its entries to shard t % JTK_Q_SHARDS with one returning
 // atomic per tile and bin.  Entry: pos (40 bits) | len << 40 (10 bits) | tokens in its tile << 50 (set by the merge).
-#define JTK_NBINS 3
+#define JTK_NBINS 5
 #define JTK_Q_SHARDS 64
 #define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
 #define JTK_BIN_CAP1 (JTK_TILE / 16)   //           17..32 bytes
 #define JTK_BIN_CAP2 (JTK_TILE / 32)   //           33..64 bytes
+#define JTK_BIN_CAP3 (JTK_TILE / 64)   //           65..128 bytes
+#define JTK_BIN_CAP4 (JTK_TILE / 128)  //           129..256 bytes
+#define JTK_BIN_MAXLEN 256            // longer pieces go to the wave-per-piece kernels
 #define JTK_M_WGS_PER_SHARD 4
 #define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
 #define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin (= JTK_MAX_PIECE_BYTES)

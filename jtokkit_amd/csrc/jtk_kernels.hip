@@ -379,6 +379,8 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __shared__ uint32_t s_q0[JTK_BIN_CAP0];      // this tile's pieces for the merge kernels, by bin: offset | len << 12
     __shared__ uint32_t s_q1[JTK_BIN_CAP1];
     __shared__ uint32_t s_q2[JTK_BIN_CAP2];
+    __shared__ uint32_t s_q3[JTK_BIN_CAP3];
+    __shared__ uint32_t s_q4[JTK_BIN_CAP4];
     __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_hits;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
@@ -456,6 +458,8 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
             } else if (len <= 16) bin = 0;
             else if (len <= 32) bin = 1;
             else if (len <= 64) bin = 2;
+            else if (len <= 128) bin = 3;
+            else if (len <= JTK_BIN_MAXLEN) bin = 4;
             else {
                 const int64_t len64 = ((k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B)) - s;
                 if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
@@ -471,7 +475,7 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
                 if (lane == 0) base = atomicAdd(&s_qn[q], (uint32_t)__popcll(bal));
                 base = (uint32_t)__shfl((int)base, 0);
                 if (bin == q) {
-                    uint32_t* dst = q == 0 ? s_q0 : (q == 1 ? s_q1 : s_q2);
+                    uint32_t* dst = q == 0 ? s_q0 : q == 1 ? s_q1 : q == 2 ? s_q2 : q == 3 ? s_q3 : s_q4;
                     dst[base + __popcll(bal & lanemask_lt())] = entry;
                 }
             }
@@ -506,7 +510,7 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < JTK_NBINS; q++) {
-        const uint32_t* src = q == 0 ? s_q0 : (q == 1 ? s_q1 : s_q2);
+        const uint32_t* src = q == 0 ? s_q0 : q == 1 ? s_q1 : q == 2 ? s_q2 : q == 3 ? s_q3 : s_q4;
         uint64_t* dst = w.q[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + s_qbase[q];
         const uint32_t nq = s_qn[q];
         for (uint32_t i = tid; i < nq; i += 256) {
@@ -529,12 +533,50 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
 // ranks): setting a piece up needs no global lookups; only the (left id, right id) pair table is read
 // from L2.  The two expensive divergent steps (EXPAND, EMIT) run when a batch of lanes has gathered.
 // Leftmost-minimum (:236): min over key = rank << 9 | slot.
-// One instantiation per length bin: <16 slots, 1024 lanes>, <32, 512>, <64, 256> -- 128 KiB of parts each.
+// One instantiation per length bin: <16 slots, 1024 lanes>, <32, 512>, <64, 256>, <128, 128>, <256, 64> --
+// 128 KiB of parts each.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t RKP_NONE = 0xFFFFFFFFu;
 constexpr int M_CHUNK = 2048;                  // queue entries a workgroup takes at a time
 
 __device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t x1, uint32_t x0) { return (x1 & m) | (x0 & ~m); }
+
+// live-part bit masks of up to 256 bits, kept in registers (every word index is an unrolled constant)
+template <int NW> __device__ __forceinline__ int mask_next_after(const uint64_t (&w)[NW], int p) {   // first set bit > p, or -1
+    int res = -1;
+#pragma unroll
+    for (int k = NW - 1; k >= 0; k--) {
+        uint64_t m = w[k];
+        const int base = k * 64;
+        if (p >= base + 63) m = 0;
+        else if (p >= base) m &= ~((2ull << (p - base)) - 1ull);
+        if (m) res = base + jtk_ctz64(m);
+    }
+    return res;
+}
+template <int NW> __device__ __forceinline__ int mask_prev_before(const uint64_t (&w)[NW], int p) {  // last set bit < p, or -1
+    int res = -1;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        uint64_t m = w[k];
+        const int base = k * 64;
+        if (p <= base) m = 0;
+        else if (p < base + 64) m &= (1ull << (p - base)) - 1ull;
+        if (m) res = base + 63 - jtk_clz64(m);
+    }
+    return res;
+}
+template <int NW> __device__ __forceinline__ void mask_clear(uint64_t (&w)[NW], int j) {
+#pragma unroll
+    for (int k = 0; k < NW; k++) { const uint64_t hit = 0ull - (uint64_t)((j >> 6) == k); w[k] &= ~((1ull << (j & 63)) & hit); }
+}
+template <int NW> __device__ __forceinline__ void mask_init(uint64_t (&w)[NW], int len) {
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const int r = len - k * 64;
+        w[k] = r >= 64 ? ~0ull : (r > 0 ? ((1ull << r) - 1ull) : 0ull);
+    }
+}
 
 template <int SLOTS, int THREADS, int BIN>
 __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
@@ -570,7 +612,9 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     uint32_t qi = 0;
     int64_t pos = 0;
     int len = 0, tpart = 0;
-    uint64_t alive = 0;
+    constexpr int NW = (SLOTS + 63) / 64;
+    uint64_t alive[NW];
+    mask_init<NW>(alive, 0);
     const uint4* const dummy = reinterpret_cast<const uint4*>(pt.buckets);
 
     for (;;) {
@@ -588,14 +632,13 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
             if (m != RKP_NONE) {                                                             // :247
                 merging = true;
                 minr = m >> 9; mini = m & 511u;
-                const uint64_t above = alive & ~((2ull << mini) - 1ull);
-                nxt = (uint32_t)jtk_ctz64(above);
-                const uint64_t above2 = above & (above - 1ull);
-                has_nn = above2 != 0;
-                nn = has_nn ? (uint32_t)jtk_ctz64(above2) : 0u;
-                const uint64_t below = alive & ((1ull << mini) - 1ull);
-                has_pv = below != 0;
-                pv = has_pv ? 63u - (uint32_t)jtk_clz64(below) : 0u;
+                nxt = (uint32_t)mask_next_after<NW>(alive, (int)mini);
+                const int nn_i = mask_next_after<NW>(alive, (int)nxt);
+                has_nn = nn_i >= 0;
+                nn = has_nn ? (uint32_t)nn_i : 0u;
+                const int pv_i = mask_prev_before<NW>(alive, (int)mini);
+                has_pv = pv_i >= 0;
+                pv = has_pv ? (uint32_t)pv_i : 0u;
                 idnn = id[nn * THREADS];
                 idpv = id[pv * THREADS];
             } else st = ST_EMIT;                                                             // :261
@@ -666,7 +709,7 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
             rk[mini * THREADS] = (r1 == JTK_RANK_NONE) ? RKP_NONE : ((r1 << 9) | mini);             // :254
             rk[nxt * THREADS] = RKP_NONE;
             id[mini * THREADS] = minr;
-            alive &= ~(1ull << nxt);                                                                // :259
+            mask_clear<NW>(alive, (int)nxt);                                                        // :259
         }
         // (5) expand parked pieces: bytes at `pos` -> single-byte ids and 2-byte-token ranks (:206-221)
         const uint64_t b_exp = __ballot(st == ST_EXPAND);
@@ -713,7 +756,7 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
                         id[j * THREADS] = s_brank[bpi >> 8];
                     }
                 }
-                alive = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);
+                mask_init<NW>(alive, len);
                 st = ST_MERGE;
             }
         }
@@ -728,17 +771,20 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
                 if (SLOTS <= 16) {
 #pragma unroll
                     for (int j = 0; j < SLOTS; j++) {
-                        if ((alive >> j) & 1ull) {
+                        if ((alive[0] >> j) & 1ull) {
                             w.tok_at[pos + j] = id[j * THREADS];
                             if (pos + j < tile_end) c0++; else c1++;
                         }
                     }
                 } else {
-                    for (uint64_t m = alive; m;) {
-                        const int j = jtk_ctz64(m);
-                        m &= m - 1;
-                        w.tok_at[pos + j] = id[j * THREADS];
-                        if (pos + j < tile_end) c0++; else c1++;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        for (uint64_t m = alive[k]; m;) {
+                            const int j = k * 64 + jtk_ctz64(m);
+                            m &= m - 1;
+                            w.tok_at[pos + j] = id[j * THREADS];
+                            if (pos + j < tile_end) c0++; else c1++;
+                        }
                     }
                 }
                 queue[qi] = (uint64_t)pos | ((uint64_t)len << 40) | ((uint64_t)c0 << 50);
@@ -950,6 +996,8 @@ void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_
     hipLaunchKernelGGL((k_bpe_merge<16, 1024, 0>), grid, dim3(1024), 0, s, w, t);
     hipLaunchKernelGGL((k_bpe_merge<32, 512, 1>), grid, dim3(512), 0, s, w, t);
     hipLaunchKernelGGL((k_bpe_merge<64, 256, 2>), grid, dim3(256), 0, s, w, t);
+    hipLaunchKernelGGL((k_bpe_merge<128, 128, 3>), grid, dim3(128), 0, s, w, t);
+    hipLaunchKernelGGL((k_bpe_merge<256, 64, 4>), grid, dim3(64), 0, s, w, t);
     hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 255) / 256)), dim3(256), 0, s, w);
 }
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
