@@ -34,6 +34,7 @@ struct JtkDeviceTables {
     JtkTok8Table tok8;
     const uint32_t* bp_rank;     // [65536]
     JtkBpLds bp;                 // the same, compressed (staged into LDS by bpe_merge)
+    const uint32_t* pair_in_token;   // [2048] bit (b0 << 8 | b1): adjacent inside some table entry
     int kind;
     int n_specials;
     uint8_t special_len[JTK_MAX_SPECIALS];

@@ -228,6 +228,7 @@ template <int KIND>
 __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[S_TX2];
     __shared__ uint64_t s_dm[S_WIN2 / 64 + 1];
+    __shared__ uint32_t s_pin[2048];           // byte pairs that occur inside some table entry
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
@@ -245,6 +246,7 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
         const int64_t wd = (lo >> 6) + i;
         s_dm[i] = (wd >= 0 && wd < w.n_words) ? w.docmask[wd] : 0ull;
     }
+    for (int i = tid; i < 2048; i += 256) s_pin[i] = t.pair_in_token[i];
     __syncthreads();
 
     // ---- phase 1: lane l gets the masks of window block wv*SPW + l
@@ -252,8 +254,14 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
     JtkBlk cu;
     cu.L = cu.N = cu.W = cu.CONT = cu.NL = cu.SP = cu.DS = cu.AP = 0;
     cu.S1 = cu.RV = cu.E = cu.LL = cu.C5 = cu.BF = 0;
+    uint64_t cut = 0;                          // bytes that cannot share a part with the byte before them
     for (int l = 0; l < 64; l++) {
         const JtkBlk k = classify_block<KIND>(s_tx, s_dm, wb0 + l, lo, n, t.uc);
+        {
+            const int i = (wb0 + l) * 64 + lane;
+            const uint32_t pi = ((uint32_t)s_tx[i + 3] << 8) | s_tx[i + 4];
+            cut = writelane64(__ballot(!((s_pin[pi >> 5] >> (pi & 31u)) & 1u)), l, cut);
+        }
         cu.L = writelane64(k.L, l, cu.L);       cu.N = writelane64(k.N, l, cu.N);
         cu.W = writelane64(k.W, l, cu.W);       cu.CONT = writelane64(k.CONT, l, cu.CONT);
         cu.NL = writelane64(k.NL, l, cu.NL);    cu.SP = writelane64(k.SP, l, cu.SP);
@@ -331,7 +339,10 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
         if (p0 + 63 <= n) valid = ~0ull;
         else if (p0 <= n) valid = (2ull << (n - p0)) - 1ull;
         const int64_t wd = p0 >> 6;
-        if (wd < w.n_words) w.piecemask[wd] = ms & valid;
+        // Extra cuts inside regex pieces: where two bytes never occur next to each other inside any table
+        // entry no merge can cross (every part is a table entry), so bytePairMerge of the piece equals
+        // the concatenation of bytePairMerge of the two sides.  Long CJK runs fall apart into a few bytes each.
+        if (wd < w.n_words) w.piecemask[wd] = (ms | cut) & valid;
     }
 }
 

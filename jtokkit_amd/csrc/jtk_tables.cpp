@@ -173,6 +173,17 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         shorts.push_back(JtkTok8Slot{lo, hi, kv.second, (uint32_t)T.size()});
     }
     t.n_tok8 = (int64_t)shorts.size();
+    // Bytes b0 b1 that never sit next to each other inside any table entry can never end up in one part:
+    // every merge result is a table entry.  bytePairMerge therefore never merges across such a position,
+    // the sub-pieces on either side merge independently, and the split kernel may cut there.
+    t.pair_in_token.assign(2048, 0);
+    for (auto& kv : t.bytes_to_id) {
+        const std::string& T = kv.first;
+        for (size_t k = 0; k + 1 < T.size(); k++) {
+            const uint32_t i = ((uint32_t)(uint8_t)T[k] << 8) | (uint8_t)T[k + 1];
+            t.pair_in_token[i >> 5] |= 1u << (i & 31u);
+        }
+    }
     {
         t.bp_bits.assign(1024, 0);
         t.bp_cum.assign(1024, 0);

@@ -23,6 +23,7 @@ struct JtkHostTables {
     int64_t n_tok8 = 0;
     std::vector<uint32_t> bp_rank;               // [65536] rank of the 2-byte token (b0 << 8 | b1), or NONE
     // the same table compressed for LDS: membership bitmap, per-word running count, ranks in index order
+    std::vector<uint32_t> pair_in_token;         // [2048] bit (b0 << 8 | b1): the two bytes are adjacent inside some table entry
     std::vector<uint64_t> bp_bits;               // [1024]
     std::vector<uint16_t> bp_cum;                // [1024]
     std::vector<uint32_t> bp_ranks;              // [n_bp] (padded to JTK_BP_MAX)
