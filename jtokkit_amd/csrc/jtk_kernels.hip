@@ -14,6 +14,7 @@
 #include "jtk_kernels.h"
 
 #include "jtk_merge_core.h"
+#include "jtk_block_classify.h"
 #include "jtk_split_masks.h"
 #include "jtk_split_rules.h"
 
@@ -118,21 +119,19 @@ __global__ void __launch_bounds__(256) k_special_check(JtkWork w, JtkDeviceTable
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pretok_split: one lane per byte classifies, __ballot turns the predicates into 64-bit masks, and the
-// split rules are scalar bit algebra per 64-byte block (jtk_split_masks.h).  Each wave walks 16
-// consecutive blocks of its workgroup's 4 KiB tile, carrying the block-to-block state in registers.
+// pretok_split: ONE LANE PER 64-BYTE BLOCK.  A lane loads its block (4 x 16 B), classifies it through a
+// 256-entry byte-code table in LDS plus 8x8 bit transposes (jtk_block_classify.h), and evaluates the
+// split rules for the whole block as 64-bit mask algebra (jtk_split_masks.h).  Block-to-block carries
+// (digit-run phase, swallowed CR/LF chains, ...) are exchanged with __shfl_up and iterated to a fixed
+// point: one or two rounds unless a run spans several blocks.  Lanes 0 and 63 of a wave are halo
+// blocks, so a wave emits 62 mask words with one coalesced store; a workgroup covers 15,872 bytes.
 // ---------------------------------------------------------------------------------------------------
-constexpr int ST = JTK_SPLIT_TILE, SH = JTK_SPLIT_HALO;
-constexpr int S_WIN = ST + 2 * SH;         // window [B-SH, B+ST+SH)
-constexpr int S_TX = S_WIN + 8;            // text kept in LDS: [B-SH-4, B+ST+SH+4)
-static_assert(SH == 64, "one halo block on each side");
-
 struct GlobalText {
     const uint8_t* t; int64_t n;
     __device__ uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
 };
 
-// Unbounded window over global memory (runs longer than the halo; rare, exact).
+// Unbounded window over global memory for the rare positions that need a run walk (exact).
 struct SlowWin {
     typedef int64_t idx_t;
     static constexpr int kMaxWalk = 0;
@@ -147,76 +146,9 @@ struct SlowWin {
     }
 };
 
-struct LdsText {                            // index = window-relative position (0 = B - SH)
-    const uint8_t* txv;
-    __device__ uint32_t byte(int i) const { return txv[i + 4]; }
-};
-
-// Window-relative 32-bit indices, class bytes computed from the LDS text; run walks are capped inside the halo.
-struct FastWin {
-    typedef int idx_t;
-    static constexpr int kMaxWalk = SH - 8;
-    const uint8_t* txv; const uint64_t* dm; int64_t lo; int64_t n; JtkUcTables uc;
-    __device__ uint32_t byte(int i) const { return txv[i + 4]; }
-    __device__ uint32_t cb(int i) const {
-        const int64_t p = lo + i;
-        if (p >= n) return JTK_CB_DS;
-        LdsText lt{txv};
-        uint32_t c = jtk_class_byte(lt, uc, i);
-        if ((dm[i >> 6] >> (i & 63)) & 1ull) c |= JTK_CB_DS;
-        return c;
-    }
-};
-
-template <int KIND>
-__device__ __forceinline__ JtkBlk classify_block(const uint8_t* s_tx, const uint64_t* s_dm, int wb, int64_t lo, int64_t n,
-                                                 const JtkUcTables& uc) {
-    const int lane = threadIdx.x & 63;
-    const int i = wb * 64 + lane;
-    const int64_t p = lo + i;
-    uint32_t c = 0, raw = 0;
-    if (p >= n) c = JTK_CB_DS;
-    else if (p >= 0) {
-        raw = s_tx[i + 4];
-        LdsText lt{s_tx};
-        c = jtk_class_byte(lt, uc, i);
-        if ((s_dm[wb] >> lane) & 1ull) c |= JTK_CB_DS;
-    }
-    const uint32_t cls = c & JTK_CB_CLS;
-    const uint32_t f = (KIND == JTK_PAT_CL100K && (raw - 'A') < 26u) ? (raw | 0x20u) : raw;
-    JtkBlk k;
-    k.L = __ballot(cls == JTK_CLS_L);
-    k.N = __ballot(cls == JTK_CLS_N);
-    k.W = __ballot(cls == JTK_CLS_W);
-    k.CONT = __ballot((c & JTK_CB_CONT) != 0);
-    k.NL = __ballot((c & JTK_CB_NL) != 0);
-    k.SP = __ballot((c & JTK_CB_SP) != 0);
-    k.DS = __ballot((c & JTK_CB_DS) != 0);
-    k.AP = __ballot(raw == '\'');
-    k.S1 = __ballot(f == 's' || f == 't' || f == 'm' || f == 'd');
-    k.RV = __ballot(f == 'r' || f == 'v');
-    k.E = __ballot(f == 'e');
-    k.LL = __ballot(f == 'l');
-    k.C5 = __ballot(raw == 0xC5u);
-    k.BF = __ballot(raw == 0xBFu);
-    return k;
-}
-
-// Two phases per wave.  (1) Byte-parallel: for each of 64 consecutive blocks the wave classifies one
-// byte per lane and the ballot masks are deposited in the registers of lane l (one select per dword), so that
-// afterwards LANE l OWNS BLOCK l.  (2) Block-parallel: every lane runs the mask algebra of
-// jtk_split_masks.h for its own block with 64-bit VALU ops; the block-to-block carries (swallowed
-// CR/LF chains, digit-run phase, ...) are exchanged with __shfl_up and iterated to a fixed point
-// (one or two rounds unless a run spans several blocks).  Lanes 0 and 63 are halo blocks: a wave
-// emits 62 mask words, a workgroup 248 (15,872 bytes of text).
 constexpr int SPW = 62;                                // blocks a wave emits
 constexpr int SPLIT_BYTES = 4 * SPW * 64;              // bytes per workgroup
-constexpr int S_WIN2 = SPLIT_BYTES + 2 * 64;           // window [B-64, B+SPLIT_BYTES+64)
-constexpr int S_TX2 = S_WIN2 + 8;
 
-__device__ __forceinline__ uint64_t writelane64(uint64_t v, int l, uint64_t old) {
-    return ((int)(threadIdx.x & 63u) == l) ? v : old;          // v is wave-uniform: a select per dword
-}
 __device__ __forceinline__ uint64_t hi_from_prev_lane(uint64_t v) {      // only the top bits are consumed
     return (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1) << 32;
 }
@@ -226,52 +158,63 @@ __device__ __forceinline__ uint64_t lo_from_next_lane(uint64_t v) {      // only
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables t) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tx[S_TX2];
-    __shared__ uint64_t s_dm[S_WIN2 / 64 + 1];
+    __shared__ uint16_t s_codes[256];          // per-byte flag codes (jtk_byte_code)
     __shared__ uint32_t s_pin[2048];           // byte pairs that occur inside some table entry
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
-    const int64_t lo = B - 64, tlo = lo - 4;
     const int64_t n = w.n_bytes;
-
-    for (int i = tid; i < S_TX2 / 4; i += 256) {
-        const int64_t p = tlo + (int64_t)i * 4;
-        uint32_t v = 0;
-        if (p >= 0 && p + 4 <= n) v = *reinterpret_cast<const uint32_t*>(w.text + p);
-        else for (int j = 0; j < 4; j++) { const int64_t q = p + j; if (q >= 0 && q < n) v |= (uint32_t)w.text[q] << (8 * j); }
-        reinterpret_cast<uint32_t*>(s_tx)[i] = v;
-    }
-    for (int i = tid; i < S_WIN2 / 64 + 1; i += 256) {
-        const int64_t wd = (lo >> 6) + i;
-        s_dm[i] = (wd >= 0 && wd < w.n_words) ? w.docmask[wd] : 0ull;
-    }
+    s_codes[tid] = (uint16_t)jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
     for (int i = tid; i < 2048; i += 256) s_pin[i] = t.pair_in_token[i];
     __syncthreads();
 
-    // ---- phase 1: lane l gets the masks of window block wv*SPW + l
-    const int wb0 = wv * SPW;
-    JtkBlk cu;
-    cu.L = cu.N = cu.W = cu.CONT = cu.NL = cu.SP = cu.DS = cu.AP = 0;
-    cu.S1 = cu.RV = cu.E = cu.LL = cu.C5 = cu.BF = 0;
-    uint64_t cut = 0;                          // bytes that cannot share a part with the byte before them
-    for (int l = 0; l < 64; l++) {
-        const JtkBlk k = classify_block<KIND>(s_tx, s_dm, wb0 + l, lo, n, t.uc);
-        {
-            const int i = (wb0 + l) * 64 + lane;
-            const uint32_t pi = ((uint32_t)s_tx[i + 3] << 8) | s_tx[i + 4];
-            cut = writelane64(__ballot(!((s_pin[pi >> 5] >> (pi & 31u)) & 1u)), l, cut);
+    // ---- this lane's block
+    const int64_t p0 = B - 64 + (int64_t)(wv * SPW + lane) * 64;
+    uint32_t d[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int64_t p = p0 + 16 * q;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p >= 0 && p + 16 <= n) v = *reinterpret_cast<const uint4*>(w.text + p);
+        else if (p >= 0 && p < n) {
+            uint32_t tmp[4] = {0, 0, 0, 0};
+            for (int r = 0; r < 16; r++) if (p + r < n) tmp[r >> 2] |= (uint32_t)w.text[p + r] << (8 * (r & 3));
+            v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
         }
-        cu.L = writelane64(k.L, l, cu.L);       cu.N = writelane64(k.N, l, cu.N);
-        cu.W = writelane64(k.W, l, cu.W);       cu.CONT = writelane64(k.CONT, l, cu.CONT);
-        cu.NL = writelane64(k.NL, l, cu.NL);    cu.SP = writelane64(k.SP, l, cu.SP);
-        cu.DS = writelane64(k.DS, l, cu.DS);    cu.AP = writelane64(k.AP, l, cu.AP);
-        cu.S1 = writelane64(k.S1, l, cu.S1);    cu.RV = writelane64(k.RV, l, cu.RV);
-        cu.E = writelane64(k.E, l, cu.E);       cu.LL = writelane64(k.LL, l, cu.LL);
-        cu.C5 = writelane64(k.C5, l, cu.C5);    cu.BF = writelane64(k.BF, l, cu.BF);
+        d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+    }
+    JtkBlk cu;
+    uint64_t lead;
+    jtk_block_masks_ascii(d, s_codes, cu, lead);
+    {
+        const GlobalText gt{w.text, n};
+        uint32_t spill;
+        jtk_block_fix_nonascii(gt, t.uc, p0, lead, cu, spill);
+        uint32_t prev_spill = (uint32_t)__shfl_up((int)spill, 1);
+        if (lane == 0) prev_spill = JTK_CLS_O;
+        jtk_block_apply_spill(cu, prev_spill);
+    }
+    {   // document starts; every position >= n counts as one
+        const int64_t wd = p0 >> 6;
+        uint64_t ds = (p0 >= 0 && wd < w.n_words) ? w.docmask[wd] : 0ull;
+        if (p0 + 63 >= n) ds |= (p0 >= n) ? ~0ull : ~((1ull << (n - p0)) - 1ull);
+        cu.DS = ds;
+    }
+    // bytes that cannot share a part with the byte before them (see the piecemask store below)
+    uint64_t cut = 0;
+    {
+        uint32_t prev = (uint32_t)__shfl_up((int)(d[15] >> 24), 1);
+        if (lane == 0) prev = (p0 > 0 && p0 <= n) ? w.text[p0 - 1] : 0u;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 255u;
+            const uint32_t pi = (prev << 8) | cur;
+            cut |= (uint64_t)(((s_pin[pi >> 5] >> (pi & 31u)) & 1u) ^ 1u) << j;
+            prev = cur;
+        }
     }
 
-    // ---- phase 2: lane = block
+    // ---- the split rules for the whole block
     JtkBlk nx;
     nx.L = nx.N = nx.NL = nx.SP = nx.AP = nx.S1 = nx.RV = nx.C5 = nx.BF = 0;
     nx.W = lo_from_next_lane(cu.W); nx.DS = lo_from_next_lane(cu.DS); nx.CONT = lo_from_next_lane(cu.CONT);
@@ -309,7 +252,6 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
     }
 
     // ---- per-position work that is not mask algebra: cl100k digit runs, and the rare slow positions
-    const int wb = wb0 + lane;
     for (uint64_t m = nlanes; m;) {
         const int j = jtk_ctz64(m);
         m &= m - 1;
@@ -321,20 +263,13 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
     for (uint64_t m = slow; m;) {
         const int j = jtk_ctz64(m);
         m &= m - 1;
-        const int i = wb * 64 + j;
-        const FastWin fw{s_tx, s_dm, lo, n, t.uc};
-        bool unresolved = false;
-        bool v = jtk_is_piece_start_t<KIND>(fw, i, unresolved);
-        if (unresolved) {
-            const SlowWin sw{w.text, n, w.docmask, t.uc};
-            bool dummy = false;
-            v = jtk_is_piece_start_t<KIND>(sw, lo + i, dummy);
-        }
+        const SlowWin sw{w.text, n, w.docmask, t.uc};
+        bool dummy = false;
+        const bool v = jtk_is_piece_start_t<KIND>(sw, p0 + j, dummy);
         ms = v ? (ms | (1ull << j)) : (ms & ~(1ull << j));
     }
 
     if (lane >= 1 && lane <= SPW) {
-        const int64_t p0 = lo + (int64_t)wb * 64;
         uint64_t valid = 0;                                           // positions <= n
         if (p0 + 63 <= n) valid = ~0ull;
         else if (p0 <= n) valid = (2ull << (n - p0)) - 1ull;

@@ -9,6 +9,7 @@
 #include "../../jtokkit_amd/csrc/jtk_common.h"
 #include "../../jtokkit_amd/csrc/jtk_split_rules.h"
 #include "../../jtokkit_amd/csrc/jtk_split_masks.h"
+#include "../../jtokkit_amd/csrc/jtk_block_classify.h"
 #include "../../jtokkit_amd/csrc/jtk_unicode_tables.h"
 
 namespace {
@@ -112,6 +113,46 @@ extern "C" int sim_split_masks(int kind, const uint8_t* text, int64_t n, const i
     if (kind == JTK_PAT_CL100K) sim_split_masks_t<JTK_PAT_CL100K>(text, n, cb.data(), wave_blocks, ms_out, n_slow);
     else sim_split_masks_t<JTK_PAT_R50K>(text, n, cb.data(), wave_blocks, ms_out, n_slow);
     return 0;
+}
+
+// block-parallel classification (jtk_block_classify.h) vs the per-byte construction: number of blocks that differ
+extern "C" int64_t sim_block_classify_check(int kind, const uint8_t* text, int64_t n) {
+    JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};
+    std::vector<uint8_t> cb((size_t)n + 1);
+    Txt txt{text, n};
+    for (int64_t p = 0; p < n; p++) cb[p] = (uint8_t)jtk_class_byte(txt, u, p);
+    const bool ci = kind == JTK_PAT_CL100K;
+    uint16_t codes[256];
+    for (int b = 0; b < 256; b++) codes[b] = (uint16_t)jtk_byte_code((uint32_t)b, ci);
+    const int64_t nblk = (n + 63) / 64;
+    int64_t bad = 0;
+    uint32_t spill = JTK_CLS_O;
+    for (int64_t b = 0; b < nblk; b++) {
+        uint32_t d[16];
+        for (int q = 0; q < 16; q++) {
+            uint32_t v = 0;
+            for (int r = 0; r < 4; r++) { const int64_t p = b * 64 + q * 4 + r; if (p < n) v |= (uint32_t)text[p] << (8 * r); }
+            d[q] = v;
+        }
+        JtkBlk k;
+        memset(&k, 0, sizeof(k));
+        uint64_t lead = 0;
+        jtk_block_masks_ascii(d, codes, k, lead);
+        uint32_t my_spill;
+        jtk_block_fix_nonascii(txt, u, b * 64, lead, k, my_spill);
+        jtk_block_apply_spill(k, spill);
+        spill = my_spill;
+        JtkBlk ref = make_blk(text, n, cb.data(), b, ci);
+        // bytes beyond n: the reference construction sets DS only; zero bytes classify as O in both
+        const uint64_t valid = (b * 64 + 64 <= n) ? ~0ull : ((1ull << (n - b * 64)) - 1ull);
+        const bool same = ((k.L ^ ref.L) & valid) == 0 && ((k.N ^ ref.N) & valid) == 0 && ((k.W ^ ref.W) & valid) == 0 &&
+                          ((k.CONT ^ ref.CONT) & valid) == 0 && ((k.NL ^ ref.NL) & valid) == 0 && ((k.SP ^ ref.SP) & valid) == 0 &&
+                          ((k.AP ^ ref.AP) & valid) == 0 && ((k.S1 ^ ref.S1) & valid) == 0 && ((k.RV ^ ref.RV) & valid) == 0 &&
+                          ((k.E ^ ref.E) & valid) == 0 && ((k.LL ^ ref.LL) & valid) == 0 && ((k.C5 ^ ref.C5) & valid) == 0 &&
+                          ((k.BF ^ ref.BF) & valid) == 0;
+        if (!same) bad++;
+    }
+    return bad;
 }
 
 extern "C" {
