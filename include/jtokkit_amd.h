@@ -39,7 +39,8 @@ typedef enum jtk_status {
     JTK_ERR_HIP = -8,                 /* a HIP call failed; see jtk_last_error() */
     JTK_ERR_UNSUPPORTED_TABLE = -9,   /* rank table outside what the device path handles (see
                                          jtk_encoding_create) */
-    JTK_ERR_PIECE_TOO_LONG = -10,     /* a single pre-token piece exceeds JTK_MAX_PIECE_BYTES */
+    JTK_ERR_PIECE_TOO_LONG = -10,     /* a single unsplittable pre-token piece exceeds JTK_MAX_PIECE_BYTES (1 MiB;
+                                         the reference spends O(n^2) on such a piece) */
     JTK_ERR_OUT_OF_MEMORY = -11
 } jtk_status;
 
@@ -130,7 +131,7 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
  * byte strings of `ids`; *len receives the byte count (out may be NULL to size). */
 int jtk_decode(const jtk_encoding* enc, const int32_t* ids, int64_t n, uint8_t* out, int64_t cap, int64_t* len);
 
-#define JTK_MAX_PIECE_BYTES 8192
+#define JTK_MAX_PIECE_BYTES (1 << 20)
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,8 @@ struct jtk_batch {
     DevBuf in_text, in_off;          // staging for the host-buffer entry point
     DevBuf zeroed;                   // docmask | status | result | list counters
     DevBuf piecemask, tokmask, blk_pre, tok_at, tile_cnt, tile_off, queues, q_meta, mid_list, long_list,
-        tokens, tok_off;
+        giant_list, giant_off, giant_scratch, tokens, tok_off;
+    bool giants_pending = false;
     JtkResult* host_result = nullptr;   // pinned
     JtkWork work{};
     bool have_result = false, synced = false;
@@ -75,6 +76,32 @@ struct jtk_batch {
 };
 
 #include "jtk_unicode_tables.h"
+
+
+// Second phase for pieces longer than JTK_LONG_CAP (rare: a run of one byte value, mostly).  The first
+// phase only lists them; once the host has seen the count it sizes the scratch, runs the giant-piece
+// kernel and redoes the scan and the pack.  Called after the first phase has been synchronised.
+static int finish_giants(jtk_batch* b) {
+    if (!b->giants_pending) return JTK_OK;
+    b->giants_pending = false;
+    const uint32_t ng = b->host_result->n_giant;
+    if (ng == 0) return JTK_OK;
+    hipStream_t s = b->last_stream;
+    std::vector<JtkLongPiece> list(ng);
+    HIP_TRY(hipMemcpy(list.data(), b->work.giant_list, ng * sizeof(JtkLongPiece), hipMemcpyDeviceToHost));
+    std::vector<int64_t> off(ng + 1, 0);
+    for (uint32_t i = 0; i < ng; i++) off[i + 1] = off[i] + list[i].len;
+    int rc;
+    if ((rc = b->giant_off.ensure((ng + 1) * 8)) || (rc = b->giant_scratch.ensure((size_t)off[ng] * 8 + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(b->giant_off.p, off.data(), (ng + 1) * 8, hipMemcpyHostToDevice, s));
+    jtk_launch_bpe_merge_giant(b->work, b->enc->dt, ng, (const int64_t*)b->giant_off.p, (uint32_t*)b->giant_scratch.p, s);
+    jtk_launch_tile_scan(b->work, s);
+    jtk_launch_pack(b->work, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->host_result, b->work.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return JTK_OK;
+}
 
 extern "C" {
 
@@ -196,6 +223,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     (void)hipStreamSynchronize(b->stream);
     DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->tokmask, &b->blk_pre, &b->tok_at,
                       &b->tile_cnt, &b->tile_off, &b->queues, &b->q_meta, &b->mid_list, &b->long_list,
+                      &b->giant_list, &b->giant_off, &b->giant_scratch,
                       &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
     if (b->ev_ok) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
@@ -249,6 +277,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
         (rc = b->q_meta.ensure(nt * 4 * 2 * JTK_NBINS)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
+        (rc = b->giant_list.ensure(((size_t)n_bytes / JTK_LONG_CAP + 2) * sizeof(JtkLongPiece))) ||
         (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
         (rc = b->tok_off.ensure(((size_t)n_docs + 1) * 8)))
         return rc;
@@ -279,6 +308,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     }
     w.mid_list = (JtkLongPiece*)b->mid_list.p;
     w.long_list = (JtkLongPiece*)b->long_list.p;
+    w.giant_list = (JtkLongPiece*)b->giant_list.p;
     w.tokens = (int32_t*)b->tokens.p;
     w.tok_off = (int64_t*)b->tok_off.p;
 
@@ -309,10 +339,12 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     b->have_result = true;
     b->synced = false;
     b->last_stream = s;
+    b->giants_pending = true;
     b->ev_recorded = prof;
     if (n_tokens) {
         HIP_TRY(hipStreamSynchronize(s));
         b->synced = true;
+        if ((rc = finish_giants(b)) != JTK_OK) return rc;
         *n_tokens = b->host_result->n_tokens;
     }
     return JTK_OK;
@@ -343,6 +375,7 @@ int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* 
     if (!b || !b->have_result) return fail(JTK_ERR_INVALID_ARGUMENT, "no encode has run on this batch");
     HIP_TRY(hipSetDevice(b->enc->device));
     if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
+    { const int rcg = finish_giants(b); if (rcg != JTK_OK) return rcg; }
     if (n_tokens) *n_tokens = b->host_result->n_tokens;
     if (n_docs) *n_docs = b->work.n_docs;
     if (worst_status) *worst_status = b->host_result->worst_status;

@@ -23,7 +23,9 @@
 #define JTK_BIN_MAXLEN 256            // longer pieces go to the wave-per-piece kernels
 #define JTK_M_WGS_PER_SHARD 4
 #define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
-#define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin (= JTK_MAX_PIECE_BYTES)
+#define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin
+#define JTK_GIANT_CAP (1 << 20)  // workgroup-per-piece kernel with parts in global scratch (= JTK_MAX_PIECE_BYTES)
+#define JTK_GIANT_CHUNK 256      // positions per cached chunk minimum
 #define JTK_MAX_SPECIALS 8
 #define JTK_SPECIAL_MAXLEN 32
 
@@ -49,7 +51,7 @@ struct JtkLongPiece {
 struct JtkResult {
     int64_t n_tokens;
     int32_t worst_status;
-    uint32_t pad;
+    uint32_t n_giant;       // pieces longer than JTK_LONG_CAP, handled in a second phase after a host check
 };
 
 // Device-side working set of one encode call (all pointers into the batch's scratch).
@@ -74,6 +76,7 @@ struct JtkWork {
     uint32_t* q_n[JTK_NBINS];       // [n_tiles] ... and how many there are
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
+    JtkLongPiece* giant_list;// pieces longer than JTK_LONG_CAP (second phase)
     uint32_t* mid_count;
     uint32_t* long_count;
     int32_t* status;        // per document
@@ -88,6 +91,8 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
+                                uint32_t* scratch, hipStream_t s);
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);
 

@@ -808,8 +808,10 @@ __global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTable
         const JtkLongPiece lp = list[i];
         if (lp.len > CAP) {
             if (lane == 0) {
-                const int64_t d = find_doc(w.doc_off, w.n_docs, lp.start);
-                if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
+                if (lp.len > JTK_GIANT_CAP) {
+                    const int64_t d = find_doc(w.doc_off, w.n_docs, lp.start);
+                    if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
+                } else w.giant_list[atomicAdd(&w.result->n_giant, 1u)] = lp;     // second phase (host decides)
             }
             continue;
         }
@@ -837,6 +839,117 @@ __global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTable
             }
         }
         wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bpe_merge_giant: pieces of 8 KiB .. 1 MiB (a run of one byte value, mostly).  One workgroup per piece,
+// parts in global scratch (ids[len], rk[len]); a chunk-minimum cache in LDS (one packed key per 256
+// positions) keeps a merge at O(#chunks / 256 + 256) instead of O(len).  Rare; exact; far cheaper than the
+// reference's O(n^2) list surgery.  key = rank << 20 | position: rank first, leftmost among ties (:236).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_bpe_merge_giant(JtkWork w, JtkDeviceTables t, const int64_t* scratch_off, uint32_t* scratch) {
+    constexpr int CH = JTK_GIANT_CHUNK;
+    __shared__ uint64_t s_cmin[JTK_GIANT_CAP / CH];
+    __shared__ uint64_t s_wmin[4];
+    __shared__ int s_nb[3];                       // nxt, nn, pv
+    __shared__ uint32_t s_r[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const JtkLongPiece lp = w.giant_list[blockIdx.x];
+    const int len = (int)lp.len;
+    uint32_t* gid = scratch + 2 * scratch_off[blockIdx.x];
+    uint32_t* grk = gid + len;
+    const int nch = (len + CH - 1) / CH;
+    constexpr uint64_t KNONE = ~0ull;
+
+    for (int j = tid; j < len; j += 256) {
+        const uint32_t b0 = w.text[lp.start + j];
+        gid[j] = t.byte_rank[b0];
+        grk[j] = (j + 1 < len) ? t.bp_rank[(b0 << 8) | w.text[lp.start + j + 1]] : JTK_RANK_NONE;
+    }
+    __syncthreads();
+    auto chunk_min = [&](int c) {                 // one wave: minimum key of chunk c
+        uint64_t k = KNONE;
+        for (int q = 0; q < CH / 64; q++) {
+            const int j = c * CH + q * 64 + lane;
+            if (j < len) { const uint32_t r = grk[j]; if (r != JTK_RANK_NONE) { const uint64_t kk = ((uint64_t)r << 20) | (uint32_t)j; k = kk < k ? kk : k; } }
+        }
+        k = wave_min_u64(k);
+        if (lane == 0) s_cmin[c] = k;
+    };
+    for (int c = wv; c < nch; c += 4) chunk_min(c);
+    __syncthreads();
+
+    for (;;) {
+        uint64_t k = KNONE;
+        for (int c = tid; c < nch; c += 256) { const uint64_t kk = s_cmin[c]; k = kk < k ? kk : k; }
+        k = wave_min_u64(k);
+        if (lane == 0) s_wmin[wv] = k;
+        __syncthreads();
+        k = s_wmin[0];
+        for (int q = 1; q < 4; q++) k = s_wmin[q] < k ? s_wmin[q] : k;
+        if (k == KNONE) break;                                                               // :247,:261
+        const uint32_t minr = (uint32_t)(k >> 20);
+        const int mini = (int)(k & 0xFFFFFu);
+        // neighbours (parts are at most 128 bytes long): wave 0 finds nxt and nn, wave 1 finds pv
+        if (wv == 0) {
+            int nxt = -1, nn = -1;
+            for (int base = mini + 1; base < len && nn < 0; base += WAVE) {
+                const int j = base + lane;
+                uint64_t bal = __ballot(j < len && gid[j] != JTK_ID_DEAD);
+                if (nxt < 0 && bal) { nxt = base + jtk_ctz64(bal); bal &= bal - 1; }
+                if (nxt >= 0 && bal) nn = base + jtk_ctz64(bal);
+            }
+            if (lane == 0) { s_nb[0] = nxt; s_nb[1] = nn; s_r[0] = nn >= 0 ? jtk_pair_lookup(t.pairs, minr, gid[nn]) : JTK_RANK_NONE; }
+        } else if (wv == 1) {
+            int pv = -1;
+            for (int base = mini - 1; base >= 0 && pv < 0; base -= WAVE) {
+                const int j = base - lane;
+                const uint64_t bal = __ballot(j >= 0 && gid[j] != JTK_ID_DEAD);
+                if (bal) pv = base - jtk_ctz64(bal);
+            }
+            if (lane == 0) { s_nb[2] = pv; s_r[1] = pv >= 0 ? jtk_pair_lookup(t.pairs, gid[pv], minr) : JTK_RANK_NONE; }
+        }
+        __syncthreads();
+        const int nxt = s_nb[0], pv = s_nb[2];
+        if (tid == 0) {
+            gid[mini] = minr; grk[mini] = s_r[0];                                            // :254
+            gid[nxt] = JTK_ID_DEAD; grk[nxt] = JTK_RANK_NONE;                                // :259
+            if (pv >= 0) grk[pv] = s_r[1];                                                   // :255-257
+        }
+        __syncthreads();
+        // refresh the cached minima of the chunks that changed
+        const int c0 = mini / CH, c1 = nxt / CH, c2 = pv >= 0 ? pv / CH : c0;
+        if (wv == 0) chunk_min(c0);
+        if (wv == 1 && c1 != c0) chunk_min(c1);
+        if (wv == 2 && c2 != c0 && c2 != c1) chunk_min(c2);
+        __syncthreads();
+    }
+    // emit
+    for (int base = 0; base < len; base += 256) {
+        const int j = base + tid;
+        const bool alive = j < len && gid[j] != JTK_ID_DEAD;
+        if (alive) w.tok_at[lp.start + j] = gid[j];
+        const uint64_t bal = __ballot(alive);
+        if (lane == 0 && bal) {
+            const int64_t p0 = lp.start + base + wv * 64;
+            const int64_t tl = p0 / T;
+            const int64_t room = (tl + 1) * (int64_t)T - p0;
+            const uint64_t lo_mask = room >= 64 ? ~0ull : ((1ull << room) - 1ull);
+            const uint32_t c0 = (uint32_t)__popcll(bal & lo_mask), c1 = (uint32_t)__popcll(bal & ~lo_mask);
+            if (c0) atomicAdd(&w.tile_cnt[tl], c0);
+            if (c1) atomicAdd(&w.tile_cnt[tl + 1], c1);
+        }
     }
 }
 
@@ -949,6 +1062,10 @@ void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_merge_long<JTK_MID_CAP>, dim3(2048), dim3(64), 0, s, w, t);
     hipLaunchKernelGGL(k_bpe_merge_long<JTK_LONG_CAP>, dim3(256), dim3(64), 0, s, w, t);
+}
+void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
+                                uint32_t* scratch, hipStream_t s) {
+    if (n_giant) hipLaunchKernelGGL(k_bpe_merge_giant, dim3(n_giant), dim3(256), 0, s, w, t, scratch_off, scratch);
 }
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, w);

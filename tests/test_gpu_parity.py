@@ -148,12 +148,17 @@ def test_long_runs_and_long_pieces(jt, name):
     _assert_batch_equals_oracle(enc, o, texts)
 
 
-def test_piece_too_long_status(jt):
+def test_giant_pieces_and_limit(jt):
+    """Pieces above the LDS kernels' 8 KiB (second phase, parts in global scratch) still equal the oracle;
+    only a single unsplittable piece above 1 MiB is refused, per document."""
     enc = jt.get_encoding("cl100k_base")
-    texts = ["ok text", "a" * 9000, "more ok"]
-    res = enc.encode_batch(texts)
+    o = oracle_lib.get("cl100k_base")
+    texts = ["ok text", "a" * 9000, "more ok", " " * 20000 + "x", "=" * 12345, "ab" * 6000, "\n" * 10000]
+    res = _assert_batch_equals_oracle(enc, o, texts)
+    assert (res.status == 0).all()
+    res = enc.encode_batch(["fine", "a" * ((1 << 20) + 5), "also fine"])
     assert res.status.tolist() == [0, -10, 0]
-    assert res.doc(0).tolist() == enc.encode("ok text") and res.doc(2).tolist() == enc.encode("more ok")
+    assert res.doc(0).tolist() == enc.encode("fine") and res.doc(2).tolist() == enc.encode("also fine")
 
 
 @pytest.mark.parametrize("name", ["cl100k_base", "p50k_edit"])
