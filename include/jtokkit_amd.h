@@ -49,8 +49,11 @@ enum { JTK_PATTERN_R50K = 0, JTK_PATTERN_CL100K = 1 };
 
 /* Flags of jtk_batch_encode*. */
 enum {
-    JTK_ENCODE_ORDINARY = 1u /* encodeOrdinary(): skip the special-token check of encode()
-                                (GptBytePairEncoding.java:62-64 vs :47-59) */
+    JTK_ENCODE_ORDINARY = 1u,     /* encodeOrdinary(): skip the special-token check of encode()
+                                     (GptBytePairEncoding.java:62-64 vs :47-59) */
+    JTK_ENCODE_VALIDATE_UTF8 = 2u /* also check every document is well-formed UTF-8 (what String.getBytes(UTF_8)
+                                     produces); offenders get status JTK_ERR_BAD_UTF8.  Without the flag the
+                                     input is trusted: malformed bytes are encoded as the bytes they are. */
 };
 
 typedef struct jtk_encoding jtk_encoding;

@@ -25,6 +25,7 @@ JTK_ERR_OUT_OF_MEMORY = -11
 JTK_PATTERN_R50K = 0
 JTK_PATTERN_CL100K = 1
 JTK_ENCODE_ORDINARY = 1
+JTK_ENCODE_VALIDATE_UTF8 = 2
 
 # every symbol include/jtokkit_amd.h declares: (restype, argtypes)
 _p = C.c_void_p

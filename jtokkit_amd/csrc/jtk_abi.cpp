@@ -321,6 +321,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     jtk_launch_mark_docs(w, s);
     mark();
     if (!(flags & JTK_ENCODE_ORDINARY)) jtk_launch_special_check(w, enc->dt, s);
+    if (flags & JTK_ENCODE_VALIDATE_UTF8) jtk_launch_validate_utf8(w, s);
     mark();
     jtk_launch_pretok_split(w, enc->dt, s);
     mark();

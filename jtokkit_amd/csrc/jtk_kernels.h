@@ -87,6 +87,7 @@ struct JtkWork {
 
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);

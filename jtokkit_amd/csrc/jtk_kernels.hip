@@ -119,6 +119,53 @@ __global__ void __launch_bounds__(256) k_special_check(JtkWork w, JtkDeviceTable
 }
 
 // ---------------------------------------------------------------------------------------------------
+// validate_utf8 (optional): every document must be what String.getBytes(UTF_8) can produce -- shortest
+// form, no surrogates, <= U+10FFFF, no sequence cut by the document's end.  One lane per byte: lead bytes
+// check their sequence, continuation bytes check that a lead covers them.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_validate_utf8(JtkWork w) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= w.n_bytes) return;
+    auto ds = [&](int64_t q) { return q >= w.n_bytes || ((w.docmask[q >> 6] >> (q & 63)) & 1ull) != 0; };
+    auto at = [&](int64_t q) -> uint32_t { return (q >= 0 && q < w.n_bytes) ? w.text[q] : 0u; };
+    const uint32_t b = w.text[p];
+    bool bad = false;
+    if (b < 0x80u) return;
+    if ((b & 0xC0u) == 0x80u) {
+        // find the lead (at most 3 back, same document) and check it is long enough to cover this byte
+        bad = true;
+        int64_t q = p;
+        for (int k = 1; k <= 3; k++) {
+            if (ds(q)) break;                       // p..q start a document: no lead before them
+            q--;
+            const uint32_t c = at(q);
+            if ((c & 0xC0u) == 0x80u) continue;
+            const int len = c >= 0xF0u ? 4 : (c >= 0xE0u ? 3 : (c >= 0xC2u ? 2 : 0));
+            bad = !(c >= 0xC2u && c <= 0xF4u && len > k);
+            break;
+        }
+    } else {
+        const int len = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
+        if (b < 0xC2u || b > 0xF4u) bad = true;
+        for (int k = 1; k < len && !bad; k++) {
+            const uint32_t c = at(p + k);
+            if (ds(p + k) || (c & 0xC0u) != 0x80u) bad = true;
+        }
+        if (!bad) {
+            const uint32_t c1 = at(p + 1);
+            if (b == 0xE0u && c1 < 0xA0u) bad = true;          // overlong
+            if (b == 0xEDu && c1 > 0x9Fu) bad = true;          // surrogates
+            if (b == 0xF0u && c1 < 0x90u) bad = true;          // overlong
+            if (b == 0xF4u && c1 > 0x8Fu) bad = true;          // > U+10FFFF
+        }
+    }
+    if (bad) {
+        const int64_t d = find_doc(w.doc_off, w.n_docs, p);
+        if (d >= 0) atomicMin(&w.status[d], -6 /* JTK_ERR_BAD_UTF8 */);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // pretok_split: ONE LANE PER 64-BYTE BLOCK.  A lane loads its block (4 x 16 B), classifies it through a
 // 256-entry byte-code table in LDS plus 8x8 bit transposes (jtk_block_classify.h), and evaluates the
 // split rules for the whole block as 64-bit mask algebra (jtk_split_masks.h).  Block-to-block carries
@@ -1041,6 +1088,10 @@ void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStr
     if (t.n_specials == 0 || w.n_bytes == 0) return;
     const int64_t threads = (w.n_bytes + 15) / 16;
     hipLaunchKernelGGL(k_special_check, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w, t);
+}
+void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s) {
+    if (w.n_bytes == 0) return;
+    hipLaunchKernelGGL(k_validate_utf8, dim3((unsigned)((w.n_bytes + 255) / 256)), dim3(256), 0, s, w);
 }
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     const int64_t tiles = (w.n_bytes + 1 + SPLIT_BYTES - 1) / SPLIT_BYTES;

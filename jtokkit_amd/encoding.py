@@ -87,12 +87,13 @@ class Batch:
 
     __del__ = close
 
-    def encode_host(self, text_u8, doc_off, ordinary=False):
+    def encode_host(self, text_u8, doc_off, ordinary=False, validate=False):
         text_u8 = np.ascontiguousarray(text_u8, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
         nt = C.c_int64(0)
+        flags = (N.JTK_ENCODE_ORDINARY if ordinary else 0) | (N.JTK_ENCODE_VALIDATE_UTF8 if validate else 0)
         _check(N.lib().jtk_batch_encode(self._h, text_u8.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1,
-                                        N.JTK_ENCODE_ORDINARY if ordinary else 0, C.byref(nt)))
+                                        flags, C.byref(nt)))
         return nt.value
 
     def encode_device(self, d_text_ptr, d_doc_off_ptr, n_docs, n_bytes, ordinary=False, stream=None, sync=True):
@@ -216,18 +217,18 @@ class HipEncoding:
     getName = get_name
 
     # ---- batch -----------------------------------------------------------------------------------------
-    def encode_batch(self, texts, ordinary=False):
+    def encode_batch(self, texts, ordinary=False, validate=False):
         """List of str/bytes -> BatchResult (one jtk_batch_encode call)."""
         bs = [t if isinstance(t, (bytes, bytearray)) else t.encode("utf-8") for t in texts]
         doc_off = np.zeros(len(bs) + 1, dtype=np.int64)
         if bs:
             np.cumsum([len(b) for b in bs], out=doc_off[1:])
         text = np.frombuffer(b"".join(bs), dtype=np.uint8) if doc_off[-1] else np.zeros(0, dtype=np.uint8)
-        return self.encode_batch_packed(text, doc_off, ordinary)
+        return self.encode_batch_packed(text, doc_off, ordinary, validate)
 
-    def encode_batch_packed(self, text_u8, doc_off, ordinary=False):
+    def encode_batch_packed(self, text_u8, doc_off, ordinary=False, validate=False):
         b = self._b()
-        b.encode_host(text_u8, doc_off, ordinary)
+        b.encode_host(text_u8, doc_off, ordinary, validate)
         return b.fetch()
 
     def vocab_size(self):

@@ -148,6 +148,32 @@ def test_long_runs_and_long_pieces(jt, name):
     _assert_batch_equals_oracle(enc, o, texts)
 
 
+def test_utf8_validation_flag(jt):
+    """JTK_ENCODE_VALIDATE_UTF8: malformed documents are flagged per document; well-formed ones are not,
+    and their tokens are unaffected.  Without the flag malformed bytes still round-trip as bytes."""
+    enc = jt.get_encoding("cl100k_base")
+    good = ["plain", "caf\u00e9 \u4e2d\u6587 \U0001f355", "", "\u00e9", "\U0001f355"]
+    bad = [b"\xff", b"ab\x80", b"\xc3", b"\xe4\xb8", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xe0\x9f\xbf",
+           b"x\xf0\x9f\x8d", b"\xf8\x88\x80\x80\x80"]
+    docs = []
+    for i in range(max(len(good), len(bad))):
+        if i < len(good):
+            docs.append(good[i].encode("utf-8"))
+        if i < len(bad):
+            docs.append(bad[i])
+    exp = [(-6 if d in bad else 0) for d in docs]
+    res = enc.encode_batch(docs, ordinary=True, validate=True)
+    assert res.status.tolist() == exp
+    for i, d in enumerate(docs):
+        if d not in bad:
+            assert res.doc(i).tolist() == enc.encode_ordinary(d.decode("utf-8"))
+    # a sequence cut by the document boundary is malformed in both documents
+    res = enc.encode_batch([b"\xe4\xb8", b"\xad"], ordinary=True, validate=True)
+    assert res.status.tolist() == [-6, -6]
+    res = enc.encode_batch(docs, ordinary=True)
+    assert (res.status == 0).all() and enc.decode_bytes(res.tokens) == b"".join(docs)
+
+
 def test_giant_pieces_and_limit(jt):
     """Pieces above the LDS kernels' 8 KiB (second phase, parts in global scratch) still equal the oracle;
     only a single unsplittable piece above 1 MiB is refused, per document."""
