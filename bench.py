@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- input MB/s of the cl100k_base batch encode path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the whole hot path (mark_docs, pretok_split, bpe_merge, scan, pack -- every
+One "step" = one pass of the whole hot path (mark_docs, pretok_split, piece_resolve, bpe_merge, pack -- every
 kernel of jtk_batch_encode_device) over one batch of synthetic documents that is already resident in
 HBM, ending with the total token count on the host; for N > 1 ranks each step also all-gathers the
 per-shard token totals over RCCL and stitches the shard's token offsets into global ones.

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjtokkit_amd.so")
+LIB_PATH = os.environ.get("JTOKKIT_AMD_LIB") or os.path.join(_HERE, "libjtokkit_amd.so")   # (override: kernel experiments)
 
 JTK_OK = 0
 JTK_ERR_INVALID_ARGUMENT = -1

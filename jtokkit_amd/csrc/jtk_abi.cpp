@@ -43,8 +43,8 @@ struct DevBuf {
 };
 
 constexpr int N_STAGES = 8;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge",
-                                           "bpe_merge_long", "tile_scan", "pack"};
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge16",
+                                           "bpe_merge_bins", "bpe_merge_long", "pack"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -63,9 +63,9 @@ struct jtk_batch {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;
     DevBuf in_text, in_off;          // staging for the host-buffer entry point
-    DevBuf zeroed;                   // docmask | status | result | list counters
-    DevBuf piecemask, tokmask, blk_pre, tok_at, tile_cnt, tile_off, queues, q_meta, mid_list, long_list,
-        giant_list, giant_off, giant_scratch, tokens, tok_off;
+    DevBuf zeroed;                   // docmask | status | result | list counters | queue counters | pack scan state
+    DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, qres, q_meta, mid_list, long_list,
+        giant_list, giant_cnt, giant_off, giant_scratch, tokens, tok_off;
     bool giants_pending = false;
     JtkResult* host_result = nullptr;   // pinned
     JtkWork work{};
@@ -80,7 +80,7 @@ struct jtk_batch {
 
 // Second phase for pieces longer than JTK_LONG_CAP (rare: a run of one byte value, mostly).  The first
 // phase only lists them; once the host has seen the count it sizes the scratch, runs the giant-piece
-// kernel and redoes the scan and the pack.  Called after the first phase has been synchronised.
+// kernel and redoes the pack.  Called after the first phase has been synchronised.
 static int finish_giants(jtk_batch* b) {
     if (!b->giants_pending) return JTK_OK;
     b->giants_pending = false;
@@ -95,7 +95,7 @@ static int finish_giants(jtk_batch* b) {
     if ((rc = b->giant_off.ensure((ng + 1) * 8)) || (rc = b->giant_scratch.ensure((size_t)off[ng] * 8 + 64))) return rc;
     HIP_TRY(hipMemcpyAsync(b->giant_off.p, off.data(), (ng + 1) * 8, hipMemcpyHostToDevice, s));
     jtk_launch_bpe_merge_giant(b->work, b->enc->dt, ng, (const int64_t*)b->giant_off.p, (uint32_t*)b->giant_scratch.p, s);
-    jtk_launch_tile_scan(b->work, s);
+    HIP_TRY(hipMemsetAsync(b->work.chunk_sum, 0, ((size_t)b->work.n_tiles / 4096 + 1) * 8, s));
     jtk_launch_pack(b->work, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->host_result, b->work.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
@@ -221,8 +221,8 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->enc->device);
     (void)hipStreamSynchronize(b->stream);
-    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->tokmask, &b->blk_pre, &b->tok_at,
-                      &b->tile_cnt, &b->tile_off, &b->queues, &b->q_meta, &b->mid_list, &b->long_list,
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->plist, &b->htok, &b->docpre,
+                      &b->tile_np, &b->tile_off, &b->queues, &b->qres, &b->q_meta, &b->giant_cnt, &b->mid_list, &b->long_list,
                       &b->giant_list, &b->giant_off, &b->giant_scratch,
                       &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
@@ -249,7 +249,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     if (!b || n_docs < 0 || n_bytes < 0 || (n_bytes > 0 && !d_utf8) || !d_doc_off)
         return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
     if (((uintptr_t)d_utf8 & 15u) != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "device text must be 16-byte aligned");
-    if (n_bytes >= (int64_t)1 << 40) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large");
+    if (n_bytes >= (int64_t)1 << 37) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large (128 GiB of text per call at most)");
     const jtk_encoding* enc = b->enc;
     HIP_TRY(hipSetDevice(enc->device));
     hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : b->stream;
@@ -262,22 +262,28 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.n_words = (n_bytes + 1 + 63) / 64 + 2;
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
 
+    // zeroed per encode: docmask | status | result + list counters | queue counters | chunk sums | tile_extra
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
-    const size_t zero_bytes = mask_bytes + status_bytes + 32 + JTK_NBINS * JTK_Q_SHARDS * 4;
     const size_t nt = (size_t)w.n_tiles;
+    const size_t qcnt_bytes = JTK_NBINS * JTK_Q_SHARDS * 4;
+    const size_t n_chunks = nt / 4096 + 1;
+    const size_t scan_bytes = n_chunks * 8 + nt * 4;
+    const size_t zero_bytes = mask_bytes + status_bytes + 32 + qcnt_bytes + scan_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
+    const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
     const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
     int rc;
     if ((rc = b->zeroed.ensure(zero_bytes)) || (rc = b->piecemask.ensure(mask_bytes)) ||
-        (rc = b->tokmask.ensure(mask_bytes)) || (rc = b->blk_pre.ensure((size_t)w.n_words * 2)) ||
-        (rc = b->tok_at.ensure(nt * JTK_TILE * 4)) ||
-        (rc = b->tile_cnt.ensure(nt * 4)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
+        (rc = b->plist.ensure(nt * JTK_TILE * 4)) || (rc = b->htok.ensure(nt * JTK_TILE * 4 + 64)) ||
+        (rc = b->docpre.ensure(nt * JTK_TILE * 4)) ||
+        (rc = b->tile_np.ensure(nt * 4 * 3)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
+        (rc = b->q_meta.ensure(nt * 4 * 16)) || (rc = b->qres.ensure(nt * (size_t)JTK_Q_PER_TILE * 8 + 1024)) ||
         (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 8)) ||
-        (rc = b->q_meta.ensure(nt * 4 * 2 * JTK_NBINS)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
-        (rc = b->giant_list.ensure(((size_t)n_bytes / JTK_LONG_CAP + 2) * sizeof(JtkLongPiece))) ||
+        (rc = b->giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
+        (rc = b->giant_cnt.ensure(n_giant_max * 4)) ||
         (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
         (rc = b->tok_off.ensure(((size_t)n_docs + 1) * 8)))
         return rc;
@@ -287,25 +293,29 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.result = (JtkResult*)(z + mask_bytes + status_bytes);
     w.mid_count = (uint32_t*)(z + mask_bytes + status_bytes + 16);
     w.long_count = (uint32_t*)(z + mask_bytes + status_bytes + 20);
+    w.q_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
+    w.chunk_sum = (uint64_t*)(z + mask_bytes + status_bytes + 32 + qcnt_bytes);
+    w.tile_extra = (uint32_t*)(z + mask_bytes + status_bytes + 32 + qcnt_bytes + n_chunks * 8);
     w.piecemask = (uint64_t*)b->piecemask.p;
-    w.tokmask = (uint64_t*)b->tokmask.p;
-    w.blk_pre = (uint16_t*)b->blk_pre.p;
-    w.tok_at = (uint32_t*)b->tok_at.p;
-    w.tile_cnt = (uint32_t*)b->tile_cnt.p;
+    w.plist = (uint32_t*)b->plist.p;
+    w.htok = (uint32_t*)b->htok.p;
+    w.docpre = (uint32_t*)b->docpre.p;
+    w.tile_np = (uint32_t*)b->tile_np.p;
+    w.tile_cnt = w.tile_np + nt;
+    w.tile_tot = w.tile_np + 2 * nt;
     w.tile_off = (int64_t*)b->tile_off.p;
     {
         const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4};
         uint64_t* qp = (uint64_t*)b->queues.p;
-        uint32_t* mp = (uint32_t*)b->q_meta.p;
+        w.q_meta = (uint32_t*)b->q_meta.p;
         for (int k = 0; k < JTK_NBINS; k++) {
             w.q[k] = qp;
             w.q_cap[k] = (int64_t)(tps * caps[k]);
             qp += tps * caps[k] * JTK_Q_SHARDS;
-            w.q_base[k] = mp; mp += nt;
-            w.q_n[k] = mp; mp += nt;
         }
-        w.q_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
     }
+    w.giant_cnt = (uint32_t*)b->giant_cnt.p;
+    w.qres = (uint64_t*)b->qres.p;
     w.mid_list = (JtkLongPiece*)b->mid_list.p;
     w.long_list = (JtkLongPiece*)b->long_list.p;
     w.giant_list = (JtkLongPiece*)b->giant_list.p;
@@ -327,11 +337,11 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     mark();
     jtk_launch_piece_resolve(w, enc->dt, s);
     mark();
-    jtk_launch_bpe_merge(w, enc->dt, s);
+    jtk_launch_bpe_merge16(w, enc->dt, s);
+    mark();
+    jtk_launch_bpe_merge_bins(w, enc->dt, s);
     mark();
     jtk_launch_bpe_merge_long(w, enc->dt, s);
-    mark();
-    jtk_launch_tile_scan(w, s);
     mark();
     jtk_launch_pack(w, s);
     mark();

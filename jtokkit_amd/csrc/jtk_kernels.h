@@ -12,7 +12,15 @@
 #define JTK_TILE 2048            // bytes per piece_resolve / pack workgroup; token counts are kept per tile
 // Pieces that need bytePairMerge are queued by length bin; bin k holds pieces of up to JTK_BIN_SLOTS(k) bytes.
 // Queues are dense and sharded: tile t appends its entries to shard t % JTK_Q_SHARDS with one returning
-// atomic per tile and bin.  Entry: pos (40 bits) | len << 40 (10 bits) | tokens in its tile << 50 (set by the merge).
+// atomic per tile and bin.  Entry: pos (37 bits) | (len - 1) << 37 (8 bits) | index in the tile's list of the bin << 45.
+// The merge kernel's result for a piece is one word: (token count - 1) << 56 | up to three token ids (17 bits each,
+// bits 0..50; a piece that became more than three tokens leaves them in htok).  It replaces the queue entry and is
+// also stored in the piece's result slot qres[tile][bin offset + index].
+#define JTK_QE_POS_MASK ((1ull << 37) - 1ull)
+#define JTK_QE_LEN_SHIFT 37
+#define JTK_QE_IDX_SHIFT 45
+#define JTK_QE_CNT_SHIFT 56
+#define JTK_Q_PER_TILE (JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4)
 #define JTK_NBINS 5
 #define JTK_Q_SHARDS 64
 #define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
@@ -43,6 +51,19 @@ struct JtkDeviceTables {
     uint8_t special[JTK_MAX_SPECIALS][JTK_SPECIAL_MAXLEN];
 };
 
+// piece-list entry.  Resolved piece: token id (bits 0..16) | byte offset in the tile << 17.
+// Merged piece: JTK_PL_HARD | byte offset in the tile (bits 0..10) and either its queue entry (bin << 21 | index in
+// the tile's slice of the bin's queue << 11) or JTK_PL_NOQUEUE (wave / workgroup kernels: tokens and count in htok).
+#define JTK_PL_HARD 0x80000000u
+#define JTK_PL_NOQUEUE 0x40000000u
+#define JTK_PL_OFF_SHIFT 17
+#define JTK_PL_QI_SHIFT 11
+#define JTK_PL_BIN_SHIFT 21
+#define JTK_HT_ID_MASK 0x1FFFFu
+#define JTK_HT_CNT_SHIFT 17
+#define JTK_HT_CNT_MASK 0x3FFFu
+#define JTK_HT_ESCAPE 0x3FFFu            // count does not fit: giant piece, count in giant_cnt
+
 struct JtkLongPiece {
     int64_t start;
     int64_t len;
@@ -64,19 +85,27 @@ struct JtkWork {
     int64_t n_tiles;
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)
-    uint64_t* tokmask;      // bit p: a token starts at byte p
-    uint16_t* blk_pre;      // per 64-byte block: tokens of its tile before the block
-    uint32_t* tok_at;       // per byte position: id of the token starting there, or JTK_ID_DEAD
-    uint32_t* tile_cnt;     // tokens starting in each tile
-    int64_t* tile_off;      // exclusive scan of tile_cnt (n_tiles + 1)
+    uint32_t* plist;        // [n_tiles * JTK_TILE] per tile, packed from the tile's first word: its pieces in text order,
+                            // JTK_PL_* entry per piece (a piece belongs to the tile it starts in)
+    uint32_t* tile_np;      // [n_tiles] pieces in each tile's list
+    uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece that became more than 3 tokens, packed from the
+                            // piece's first byte position (k <= len words); word 0 also carries the count k: id | k << 17
+                            // (JTK_HT_ESCAPE: see giant_cnt)
+    uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its tile before it (sparse)
+    uint32_t* tile_cnt;     // [n_tiles] resolved pieces of the tile (one token each)
+    uint32_t* tile_extra;   // [n_tiles] tokens of the tile's pieces merged by the wave / workgroup kernels (zeroed)
+    uint32_t* tile_tot;     // [n_tiles] tokens of the tile's pieces
+    uint64_t* chunk_sum;    // [n_tiles / 4096 + 1] tokens per chunk of 4096 tiles (zeroed per scan)
+    int64_t* tile_off;      // [n_tiles + 1] exclusive scan of tile_tot
     uint64_t* q[JTK_NBINS];         // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k
     int64_t q_cap[JTK_NBINS];       // entries per shard
     uint32_t* q_count;              // [JTK_NBINS][JTK_Q_SHARDS]
-    uint32_t* q_base[JTK_NBINS];    // [n_tiles] where in its shard a tile's entries of bin k start ...
-    uint32_t* q_n[JTK_NBINS];       // [n_tiles] ... and how many there are
+    uint64_t* qres;                 // [n_tiles][JTK_Q_PER_TILE] merge results at fixed slots (only the head of each tile's block is touched)
+    uint32_t* q_meta;               // [n_tiles][16]: [k] where in its shard the tile's entries of bin k start, [8 + k] how many
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
     JtkLongPiece* giant_list;// pieces longer than JTK_LONG_CAP (second phase)
+    uint32_t* giant_cnt;    // token count per giant_list entry (0 until the second phase has run)
     uint32_t* mid_count;
     uint32_t* long_count;
     int32_t* status;        // per document
@@ -90,11 +119,11 @@ void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStr
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
-void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_bpe_merge16(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);    // pieces of <= 16 bytes
+void jtk_launch_bpe_merge_bins(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);  // 17..256 bytes
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
                                 uint32_t* scratch, hipStream_t s);
-void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);
 
 #endif

@@ -6,7 +6,7 @@
 // pretok_split    k_pretok_split    :77-80 matcher.find()/group() with EncodingFactory.java:63,105
 // bpe_merge       k_bpe_merge       :81-86 + bytePairMerge :200-275 + getRank :285-300
 // bpe_merge_long  k_bpe_merge_long  the same for pieces longer than a tile's LDS window
-// tile_scan/pack  k_tile_scan/...   out.add / addAll (:82,:117) -- document-order token stream
+// pack            k_pack_tokens     out.add / addAll (:82,:117) -- document-order token stream
 //
 // Integer / byte work only; no floating point, no MFMA.  One lane per byte in pretok_split, one
 // lane per piece in bpe_merge (short pieces) and one wave per piece with a wave-level leftmost-min
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
 // ---------------------------------------------------------------------------------------------------
 // piece_resolve: piece list of a tile; pieces of <= 8 bytes that are table entries become that one
 // token (GptBytePairEncoding.java:81-83); every other piece is queued for bytePairMerge by length.
-// Writes tok_at for the tile (token id at hit positions, DEAD elsewhere) and the tile's hit count.
+// Writes the tile's piece list (plist): one word per piece, in text order.
 // ---------------------------------------------------------------------------------------------------
 constexpr int T = JTK_TILE;
 constexpr int TW = T / 64;                                          // mask words per tile
@@ -362,19 +362,17 @@ __device__ __forceinline__ void piece_key(const uint8_t* tx, int s, int len, uin
     else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
 }
 
+constexpr int Q_OFF0 = 0, Q_OFF1 = JTK_BIN_CAP0, Q_OFF2 = Q_OFF1 + JTK_BIN_CAP1, Q_OFF3 = Q_OFF2 + JTK_BIN_CAP2,
+              Q_OFF4 = Q_OFF3 + JTK_BIN_CAP3, Q_TOTAL = Q_OFF4 + JTK_BIN_CAP4;
+
 __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
-    __shared__ __attribute__((aligned(16))) uint32_t s_id[T];
     __shared__ uint16_t s_plist[T + 1];
     __shared__ uint64_t s_pm[TW];
     __shared__ uint32_t s_cnt[TW];
     __shared__ uint32_t s_pre[TW + 1];
-    __shared__ uint32_t s_q0[JTK_BIN_CAP0];      // this tile's pieces for the merge kernels, by bin: offset | len << 12
-    __shared__ uint32_t s_q1[JTK_BIN_CAP1];
-    __shared__ uint32_t s_q2[JTK_BIN_CAP2];
-    __shared__ uint32_t s_q3[JTK_BIN_CAP3];
-    __shared__ uint32_t s_q4[JTK_BIN_CAP4];
-    __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_hits;
+    __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
+    __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -391,13 +389,14 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     }
     if (tid < TW) {
         const int64_t wd = (B >> 6) + tid;
-        const uint64_t m = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
+        uint64_t m = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
+        // the end sentinel (bit n) is not a piece
+        if ((n >> 6) == wd) m &= ~(1ull << (n & 63));
         s_pm[tid] = m;
         s_cnt[tid] = (uint32_t)__popcll(m);
     }
-    for (int i = tid; i < T / 4; i += 256) reinterpret_cast<uint4*>(s_id)[i] = make_uint4(JTK_ID_DEAD, JTK_ID_DEAD, JTK_ID_DEAD, JTK_ID_DEAD);
     if (tid < JTK_NBINS) s_qn[tid] = 0;
-    if (tid == 0) s_hits = 0;
+    if (tid == 0) s_nhard = 0;
     if (tid == 64) {
         int64_t pos = -1;                                             // scan ahead for the next piece start
         for (int64_t wd = (B >> 6) + TW; pos < 0 && wd < w.n_words; wd++) {
@@ -419,17 +418,22 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     // one lane per piece, four rounds of table probes in flight per lane
     const int64_t next_after = s_next_after;
     const JtkTok8Slot* t8 = t.tok8.slots;
-    uint32_t my_hits = 0;
+    uint32_t* const plist = w.plist + B;
     struct Probe { int s, len; uint32_t lo, hi, ax, ay, az, aw, bx, by, bz, bw; };
+    auto piece_len = [&](int k, int s) -> int64_t {
+        int64_t e;
+        if (k + 1 < np) e = s_plist[k + 1];
+        else e = (n - B < T) ? (n - B) : (next_after - B);            // last piece of the tile: ends at the sentinel
+                                                                      // (bit n) or at the next tile's first piece
+        return e - s;
+    };
     auto issue = [&](int k, Probe& pr) {
         pr.s = -1; pr.len = 0;
         if (k < np) {
             const int s = s_plist[k];
-            if (B + s < n) {                                              // the end sentinel is not a piece
-                const int64_t len64 = ((k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B)) - s;
-                pr.s = s;
-                pr.len = len64 > 0x10000 ? 0x10000 : (int)len64;
-            }
+            const int64_t len64 = piece_len(k, s);
+            pr.s = s;
+            pr.len = len64 > 0x10000 ? 0x10000 : (int)len64;
         }
         if (pr.s >= 0 && pr.len <= 8) {
             piece_key(s_tx, pr.s, pr.len, pr.lo, pr.hi);
@@ -440,39 +444,33 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         }
     };
     auto resolve = [&](int k, const Probe& pr) {
+        if (pr.s < 0) return;
+        const int s = pr.s, len = pr.len;
+        uint32_t entry = JTK_PL_HARD | JTK_PL_NOQUEUE | (uint32_t)s;
         int bin = -1;
-        if (pr.s >= 0) {
-            const int s = pr.s, len = pr.len;
-            if (len <= 8) {
-                uint32_t id = JTK_RANK_NONE;
-                if (pr.aw == (uint32_t)len && pr.ax == pr.lo && pr.ay == pr.hi) id = pr.az;
-                else if (pr.bw == (uint32_t)len && pr.bx == pr.lo && pr.by == pr.hi) id = pr.bz;
-                if (id != JTK_RANK_NONE) { s_id[s] = id; my_hits++; } else bin = 0;
-            } else if (len <= 16) bin = 0;
-            else if (len <= 32) bin = 1;
-            else if (len <= 64) bin = 2;
-            else if (len <= 128) bin = 3;
-            else if (len <= JTK_BIN_MAXLEN) bin = 4;
-            else {
-                const int64_t len64 = ((k + 1 < np) ? (int64_t)s_plist[k + 1] : (next_after - B)) - s;
-                if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
-                else w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
-            }
+        if (len <= 8) {
+            uint32_t id = JTK_RANK_NONE;
+            if (pr.aw == (uint32_t)len && pr.ax == pr.lo && pr.ay == pr.hi) id = pr.az;
+            else if (pr.bw == (uint32_t)len && pr.bx == pr.lo && pr.by == pr.hi) id = pr.bz;
+            if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT); else bin = 0;
+        } else if (len <= 16) bin = 0;
+        else if (len <= 32) bin = 1;
+        else if (len <= 64) bin = 2;
+        else if (len <= 128) bin = 3;
+        else if (len <= JTK_BIN_MAXLEN) bin = 4;
+        else {
+            const int64_t len64 = piece_len(k, s);
+            if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
+            else w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
+            atomicAdd(&s_nhard, 1u);
         }
-        const uint32_t entry = (uint32_t)(pr.s & 4095) | ((uint32_t)pr.len << 12);
-#pragma unroll
-        for (int q = 0; q < JTK_NBINS; q++) {
-            const uint64_t bal = __ballot(bin == q);
-            if (bal) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&s_qn[q], (uint32_t)__popcll(bal));
-                base = (uint32_t)__shfl((int)base, 0);
-                if (bin == q) {
-                    uint32_t* dst = q == 0 ? s_q0 : q == 1 ? s_q1 : q == 2 ? s_q2 : q == 3 ? s_q3 : s_q4;
-                    dst[base + __popcll(bal & lanemask_lt())] = entry;
-                }
-            }
+        if (bin >= 0) {
+            const int qoff = bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : Q_OFF4;
+            const uint32_t i = atomicAdd(&s_qn[bin], 1u);
+            s_q[qoff + i] = (uint32_t)s | ((uint32_t)(len - 1) << 11) | (i << 19);
+            entry = JTK_PL_HARD | ((uint32_t)bin << JTK_PL_BIN_SHIFT) | (i << JTK_PL_QI_SHIFT) | (uint32_t)s;
         }
+        plist[k] = entry;
     };
     for (int k0 = 0; k0 < np; k0 += 4 * 256) {
         Probe p0, p1, p2, p3;
@@ -485,30 +483,29 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         resolve(k0 + 512 + tid, p2);
         resolve(k0 + 768 + tid, p3);
     }
-    // hit count of the tile; the tile's slice of its queue shard is claimed with one returning atomic,
-    // issued before the tile's stores so that its latency hides under them
-    for (int d = 32; d >= 1; d >>= 1) my_hits += (uint32_t)__shfl_xor((int)my_hits, d);
-    if (lane == 0 && my_hits) atomicAdd(&s_hits, my_hits);
     __syncthreads();
+    // the tile's slices of its queue shards are claimed with one returning atomic per bin
     if (tid < JTK_NBINS) {
         const uint32_t nq = s_qn[tid];
         const uint32_t qb = nq ? atomicAdd(&w.q_count[tid * JTK_Q_SHARDS + tile % JTK_Q_SHARDS], nq) : 0u;
-        w.q_n[tid][tile] = nq;
-        w.q_base[tid][tile] = qb;
+        w.q_meta[tile * 16 + tid] = qb;
+        w.q_meta[tile * 16 + 8 + tid] = nq;
         s_qbase[tid] = qb;
     }
-    if (tid == 0) w.tile_cnt[tile] = s_hits;
-    for (int i = tid; i < T / 4; i += 256)
-        reinterpret_cast<uint4*>(w.tok_at + B)[i] = reinterpret_cast<const uint4*>(s_id)[i];
+    if (tid == 0) {
+        w.tile_np[tile] = (uint32_t)np;
+        // resolved pieces = one token each; k_tile_counts adds the merged pieces' tokens
+        w.tile_cnt[tile] = (uint32_t)np - (s_nhard + s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4]);
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < JTK_NBINS; q++) {
-        const uint32_t* src = q == 0 ? s_q0 : q == 1 ? s_q1 : q == 2 ? s_q2 : q == 3 ? s_q3 : s_q4;
+        const int qoff = q == 0 ? Q_OFF0 : q == 1 ? Q_OFF1 : q == 2 ? Q_OFF2 : q == 3 ? Q_OFF3 : Q_OFF4;
         uint64_t* dst = w.q[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + s_qbase[q];
         const uint32_t nq = s_qn[q];
         for (uint32_t i = tid; i < nq; i += 256) {
-            const uint32_t e = src[i];
-            dst[i] = (uint64_t)(B + (e & 4095u)) | ((uint64_t)(e >> 12) << 40);
+            const uint32_t e = s_q[qoff + i];
+            dst[i] = (uint64_t)(B + (e & 2047u)) | ((uint64_t)(e >> 11) << JTK_QE_LEN_SHIFT);
         }
     }
 }
@@ -602,7 +599,7 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     enum { ST_NEED = 0, ST_TEXT = 1, ST_EXPAND = 2, ST_MERGE = 3, ST_EMIT = 4, ST_DONE = 5 };
     constexpr int BATCH = 24;
     int st = ST_NEED;
-    uint32_t qi = 0;
+    uint32_t qi = 0, slot = 0;
     int64_t pos = 0;
     int len = 0, tpart = 0;
     constexpr int NW = (SLOTS + 63) / 64;
@@ -672,8 +669,9 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
         // (4) consume
         if (st == ST_NEED) {
             const uint64_t entry = (qi & 1u) ? (((uint64_t)v0.w << 32) | v0.z) : (((uint64_t)v0.y << 32) | v0.x);
-            pos = (int64_t)(entry & 0xFFFFFFFFFFull);
-            len = (int)((entry >> 40) & 1023u);
+            pos = (int64_t)(entry & JTK_QE_POS_MASK);
+            len = (int)((entry >> JTK_QE_LEN_SHIFT) & 255u) + 1;
+            slot = (uint32_t)(entry >> JTK_QE_IDX_SHIFT) & 1023u;
             tpart = 0;
             st = ST_TEXT;
         } else if (st == ST_TEXT) {
@@ -753,53 +751,51 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
                 st = ST_MERGE;
             }
         }
-        // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The number
-        // of tokens that start in the piece's own tile goes back into its queue entry (k_tile_counts sums them
-        // per tile, no atomics here); tokens spilling into the next tile are rare and counted atomically.
+        // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The result --
+        // token count and, if the piece became at most 3 tokens (most do), the tokens -- is one 8-byte word; it goes
+        // to the piece's fixed result slot (tile, bin, index) for pack and replaces the queue entry for tile_counts.
+        // Longer results go to htok, packed from the piece's first byte position.
         const uint64_t b_emit = __ballot(st == ST_EMIT);
         if (b_emit && (__popcll(b_emit) >= BATCH || !b_merge)) {
             if (st == ST_EMIT) {
-                const int64_t tile_end = (pos / T + 1) * (int64_t)T;
-                uint32_t c0 = 0, c1 = 0;
-                if (SLOTS <= 16) {
+                uint32_t c = 0;
 #pragma unroll
-                    for (int j = 0; j < SLOTS; j++) {
-                        if ((alive[0] >> j) & 1ull) {
-                            w.tok_at[pos + j] = id[j * THREADS];
-                            if (pos + j < tile_end) c0++; else c1++;
-                        }
-                    }
+                for (int k = 0; k < NW; k++) c += (uint32_t)__popcll(alive[k]);
+                uint64_t ent = (uint64_t)(c - 1) << JTK_QE_CNT_SHIFT;
+                if (c <= 3) {
+                    const int j1 = mask_next_after<NW>(alive, 0);
+                    const int j2 = j1 >= 0 ? mask_next_after<NW>(alive, j1) : -1;
+                    ent |= (uint64_t)id[0];                                             // part 0 is never merged away
+                    if (j1 >= 0) ent |= (uint64_t)id[j1 * THREADS] << 17;
+                    if (j2 >= 0) ent |= (uint64_t)id[j2 * THREADS] << 34;
                 } else {
+                    uint32_t* dst = w.htok + pos;
+                    dst[0] = id[0] | (c << JTK_HT_CNT_SHIFT);
+                    if (SLOTS <= 16) {
+                        uint32_t idx = 1;
 #pragma unroll
-                    for (int k = 0; k < NW; k++) {
-                        for (uint64_t m = alive[k]; m;) {
-                            const int j = k * 64 + jtk_ctz64(m);
-                            m &= m - 1;
-                            w.tok_at[pos + j] = id[j * THREADS];
-                            if (pos + j < tile_end) c0++; else c1++;
+                        for (int j = 1; j < SLOTS; j++) {
+                            if ((alive[0] >> j) & 1ull) { dst[idx] = id[j * THREADS]; idx++; }
+                        }
+                    } else {
+                        uint32_t idx = 0;
+#pragma unroll
+                        for (int k = 0; k < NW; k++) {
+                            for (uint64_t m = alive[k] & ~(uint64_t)(k == 0); m;) {
+                                const int j = k * 64 + jtk_ctz64(m);
+                                m &= m - 1;
+                                dst[++idx] = id[j * THREADS];
+                            }
                         }
                     }
                 }
-                queue[qi] = (uint64_t)pos | ((uint64_t)len << 40) | ((uint64_t)c0 << 50);
-                if (c1) atomicAdd(&w.tile_cnt[pos / T + 1], c1);
+                constexpr int QOFF = BIN == 0 ? Q_OFF0 : BIN == 1 ? Q_OFF1 : BIN == 2 ? Q_OFF2 : BIN == 3 ? Q_OFF3 : Q_OFF4;
+                w.qres[(pos / T) * Q_TOTAL + QOFF + slot] = ent;       // where pack finds it without an indirection
+                queue[qi] = ent;                                       // dense: k_tile_counts sums the counts
                 st = ST_NEED;
             }
         }
     }
-}
-
-// per tile: add the token counts the merge kernels left in the tile's queue entries
-__global__ void __launch_bounds__(256) k_tile_counts(JtkWork w) {
-    const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= w.n_tiles) return;
-    uint32_t c0 = 0;
-#pragma unroll
-    for (int k = 0; k < JTK_NBINS; k++) {
-        const uint32_t n = w.q_n[k][tile];
-        const uint64_t* q = w.q[k] + (tile % JTK_Q_SHARDS) * w.q_cap[k] + w.q_base[k][tile];
-        for (uint32_t i = 0; i < n; i++) c0 += (uint32_t)(q[i] >> 50) & 1023u;
-    }
-    if (c0) atomicAdd(&w.tile_cnt[tile], c0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -858,7 +854,12 @@ __global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTable
                 if (lp.len > JTK_GIANT_CAP) {
                     const int64_t d = find_doc(w.doc_off, w.n_docs, lp.start);
                     if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
-                } else w.giant_list[atomicAdd(&w.result->n_giant, 1u)] = lp;     // second phase (host decides)
+                } else {                                                          // second phase (host decides)
+                    const uint32_t gi = atomicAdd(&w.result->n_giant, 1u);
+                    w.giant_list[gi] = lp;
+                    w.giant_cnt[gi] = 0;
+                }
+                w.htok[lp.start] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;  // count: giant_cnt, or none at all
             }
             continue;
         }
@@ -870,20 +871,19 @@ __global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTable
         }
         wave_lds_fence();
         merge_piece_wave(s_id, s_rk, len, t.pairs);
+        // surviving ids, packed from the piece's first position; the count rides in word 0 (part 0 always survives)
+        uint32_t total = 0;
         for (int base = 0; base < len; base += WAVE) {
             const int j = base + lane;
             const bool alive = j < len && s_id[j] != JTK_ID_DEAD;
-            if (alive) w.tok_at[lp.start + j] = s_id[j];
             const uint64_t bal = __ballot(alive);
-            if (lane == 0 && bal) {
-                const int64_t p0 = lp.start + base;
-                const int64_t tl = p0 / T;
-                const int64_t room = (tl + 1) * (int64_t)T - p0;          // positions of this chunk in tile tl
-                const uint64_t lo_mask = room >= 64 ? ~0ull : ((1ull << room) - 1ull);
-                const uint32_t c0 = (uint32_t)__popcll(bal & lo_mask), c1 = (uint32_t)__popcll(bal & ~lo_mask);
-                if (c0) atomicAdd(&w.tile_cnt[tl], c0);
-                if (c1) atomicAdd(&w.tile_cnt[tl + 1], c1);
-            }
+            const uint32_t idx = total + (uint32_t)__popcll(bal & lanemask_lt());
+            if (alive && idx) w.htok[lp.start + idx] = s_id[j];
+            total += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) {
+            w.htok[lp.start] = s_id[0] | (total << JTK_HT_CNT_SHIFT);
+            atomicAdd(&w.tile_extra[lp.start / T], total);
         }
         wave_lds_fence();
     }
@@ -982,86 +982,202 @@ __global__ void __launch_bounds__(256) k_bpe_merge_giant(JtkWork w, JtkDeviceTab
         if (wv == 2 && c2 != c0 && c2 != c1) chunk_min(c2);
         __syncthreads();
     }
-    // emit
-    for (int base = 0; base < len; base += 256) {
-        const int j = base + tid;
-        const bool alive = j < len && gid[j] != JTK_ID_DEAD;
-        if (alive) w.tok_at[lp.start + j] = gid[j];
-        const uint64_t bal = __ballot(alive);
-        if (lane == 0 && bal) {
-            const int64_t p0 = lp.start + base + wv * 64;
-            const int64_t tl = p0 / T;
-            const int64_t room = (tl + 1) * (int64_t)T - p0;
-            const uint64_t lo_mask = room >= 64 ? ~0ull : ((1ull << room) - 1ull);
-            const uint32_t c0 = (uint32_t)__popcll(bal & lo_mask), c1 = (uint32_t)__popcll(bal & ~lo_mask);
-            if (c0) atomicAdd(&w.tile_cnt[tl], c0);
-            if (c1) atomicAdd(&w.tile_cnt[tl + 1], c1);
+    // emit (wave 0): surviving ids packed from the piece's first position; count in giant_cnt
+    if (wv == 0) {
+        uint32_t total = 0;
+        for (int base = 0; base < len; base += WAVE) {
+            const int j = base + lane;
+            const bool alive = j < len && gid[j] != JTK_ID_DEAD;
+            const uint64_t bal = __ballot(alive);
+            const uint32_t idx = total + (uint32_t)__popcll(bal & lanemask_lt());
+            if (alive && idx) w.htok[lp.start + idx] = gid[j];
+            total += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) {
+            w.htok[lp.start] = gid[0] | ((uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT);
+            w.giant_cnt[blockIdx.x] = total;
+            atomicAdd(&w.tile_extra[lp.start / T], total);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// tile_scan: exclusive scan of per-tile token counts (one workgroup)
+// tile_counts / tile_scan: tokens per tile (resolved pieces were counted by piece_resolve; the merge
+// kernels left each merged piece's count in its queue entry) and their exclusive scan.  Two small
+// kernels: a device-wide single-pass scan (decoupled look-back) was measured 4x slower here, because
+// descriptors shared between workgroups on different XCDs have to bypass the per-XCD L2s.
+//   tile_counts: 16 lanes per tile sum the tile's queue slices; one atomic per 64 tiles into the
+//                sum of its chunk of SCAN_CHUNK tiles
+//   tile_scan:   one workgroup per chunk: base = sum of the earlier chunks' sums, then a local scan
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
-    __shared__ uint64_t s_wsum[16];
-    __shared__ uint64_t s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int64_t c0 = 0; c0 < w.n_tiles; c0 += 4096) {
-        // four consecutive tiles per lane
-        const int64_t i0 = c0 + (int64_t)tid * 4;
-        uint32_t v[4];
-        uint32_t sum = 0;
-        for (int j = 0; j < 4; j++) { v[j] = (i0 + j < w.n_tiles) ? w.tile_cnt[i0 + j] : 0u; sum += v[j]; }
-        const uint32_t inc = wave_incl_scan(sum);
-        if (lane == 63) s_wsum[wv] = inc;
-        __syncthreads();
-        uint64_t before = s_base;
-        for (int k = 0; k < wv; k++) before += s_wsum[k];
-        uint64_t run = before + inc - sum;
-        for (int j = 0; j < 4; j++) { if (i0 + j < w.n_tiles) w.tile_off[i0 + j] = (int64_t)run; run += v[j]; }
-        __syncthreads();
-        if (tid == 1023) s_base = run;
-        __syncthreads();
+constexpr int SCAN_CHUNK = 4096;
+
+__global__ void __launch_bounds__(1024) k_tile_counts(JtkWork w) {
+    // 16 lanes per tile, 64 tiles per workgroup
+    __shared__ uint32_t s_sum[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane & 15;
+    const int64_t tile = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 4);
+    const bool live = tile < w.n_tiles;
+    const uint32_t meta = live ? w.q_meta[tile * 16 + g] : 0u;        // lanes 0..4: base per bin, lanes 8..12: count per bin
+    uint32_t c = 0;
+    const int gl = lane & ~15;
+#pragma unroll
+    for (int k = 0; k < JTK_NBINS; k++) {
+        const uint32_t qb = (uint32_t)__shfl((int)meta, gl + k), nq = (uint32_t)__shfl((int)meta, gl + 8 + k);
+        const uint64_t* q = w.q[k] + (tile % JTK_Q_SHARDS) * w.q_cap[k] + qb;
+        for (uint32_t i = g; i < nq; i += 16) c += ((uint32_t)(q[i] >> JTK_QE_CNT_SHIFT) & 255u) + 1u;
     }
-    if (tid == 0) {
-        w.tile_off[w.n_tiles] = (int64_t)s_base;
-        w.result->n_tokens = (int64_t)s_base;
+    for (int d = 8; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+    if (live && g == 0) {
+        c += w.tile_cnt[tile] + w.tile_extra[tile];
+        w.tile_tot[tile] = c;
+    } else c = 0;
+    for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+    if (lane == 0) s_sum[wv] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < 16; k++) t += s_sum[k];
+        if (t) atomicAdd((unsigned long long*)&w.chunk_sum[((int64_t)blockIdx.x * 64) / SCAN_CHUNK], (unsigned long long)t);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
+    __shared__ uint64_t s_part[16];
+    __shared__ uint32_t s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t chunk = blockIdx.x;
+    // tokens before this chunk
+    uint64_t b = 0;
+    for (int64_t c = tid; c < chunk; c += 1024) b += w.chunk_sum[c];
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), d);
+        b += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) s_part[wv] = b;
+    // four consecutive tiles per lane
+    const int64_t i0 = chunk * SCAN_CHUNK + (int64_t)tid * 4;
+    uint32_t v[4];
+    uint32_t sum = 0;
+    for (int j = 0; j < 4; j++) { v[j] = (i0 + j < w.n_tiles) ? w.tile_tot[i0 + j] : 0u; sum += v[j]; }
+    const uint32_t inc = wave_incl_scan(sum);
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    uint64_t before = 0;
+    for (int k = 0; k < 16; k++) before += s_part[k];
+    for (int k = 0; k < wv; k++) before += s_wsum[k];
+    uint64_t run = before + inc - sum;
+    for (int j = 0; j < 4; j++) { if (i0 + j < w.n_tiles) w.tile_off[i0 + j] = (int64_t)run; run += v[j]; }
+    if (chunk == gridDim.x - 1 && tid == 1023) {           // lanes past the last tile carry the grand total
+        w.tile_off[w.n_tiles] = (int64_t)run;
+        w.result->n_tokens = (int64_t)run;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pack: tok_at -> one packed token stream in position (= document) order; token-start masks and
-// per-block counts for the per-document offsets
+// pack: piece lists -> one packed token stream in text (= document) order.  Per tile: the exclusive
+// scan of its pieces' token counts (1 per resolved piece, the htok header count per merged piece), then
+// every piece writes its tokens at tile_off + prefix.  Also leaves, at every document's first byte, the
+// tokens of its tile before it (docpre) for k_doc_offsets.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pack_tokens(JtkWork w) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_id[T];
-    __shared__ uint64_t s_tm[TW];
-    __shared__ uint32_t s_cnt[TW];
-    __shared__ uint32_t s_pre[TW + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+__device__ __forceinline__ uint32_t hard_count(const JtkWork& w, int64_t pos) {
+    const uint32_t c = (w.htok[pos] >> JTK_HT_CNT_SHIFT) & JTK_HT_CNT_MASK;
+    if (c != JTK_HT_ESCAPE) return c;
+    const uint32_t ng = w.result->n_giant;                  // giant piece: look its count up (rare)
+    for (uint32_t i = 0; i < ng; i++)
+        if (w.giant_list[i].start == pos) return w.giant_cnt[i];
+    return 0;                                               // longer than JTK_GIANT_CAP: no tokens, status set
+}
+
+constexpr int PACK_QSTAGE = 128;               // queue entries of a tile staged in LDS (ordinary text: a few dozen)
+
+__global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
+    // ONE WAVE PER TILE.  The kernel is bound by the latency of dependent HBM reads at a fixed number of resident
+    // waves, so a wave keeps a whole tile in flight: 8 list entries per lane, the head of the tile's merge results
+    // (LDS) and the document mask are all requested before the first wait.  No workgroup barriers.
+    __shared__ uint64_t s_qe[PACK_QSTAGE];
+    __shared__ uint64_t s_dm[TW];
+    const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t B = tile * T;
-    for (int i = tid; i < T / 4; i += 256)
-        reinterpret_cast<uint4*>(s_id)[i] = reinterpret_cast<const uint4*>(w.tok_at + B)[i];
-    __syncthreads();
-    for (int blk = wv; blk < TW; blk += 4) {
-        const uint64_t bal = __ballot(s_id[blk * 64 + lane] != JTK_ID_DEAD);
-        if (lane == 0) { s_tm[blk] = bal; s_cnt[blk] = (uint32_t)__popcll(bal); }
+    const int np = (int)w.tile_np[tile];
+    const uint32_t* plist = w.plist + B;
+    uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens + w.tile_off[tile]);
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int k = j * 64 + lane; e[j] = (k < np) ? plist[k] : 0u; }
+    if (lane < TW) {
+        const int64_t dwd = (B >> 6) + lane;
+        s_dm[lane] = (dwd < w.n_words) ? w.docmask[dwd] : 0ull;
     }
-    __syncthreads();
-    if (wv == 0) wave_scan_small(s_cnt, s_pre, TW);
-    __syncthreads();
-    int32_t* dst = w.tokens + w.tile_off[tile];
-    for (int blk = wv; blk < TW; blk += 4) {
-        const uint64_t m = s_tm[blk];
-        if ((m >> lane) & 1ull) dst[s_pre[blk] + __popcll(m & lanemask_lt())] = (int32_t)s_id[blk * 64 + lane];
+    // the head of the tile's result slots, read speculatively (no dependence on the list): the first 64 of bin 0
+    // and the first 16 of bins 1..4; slots beyond are read on demand
+    const uint64_t* qres = w.qres + tile * Q_TOTAL;
+    {
+        const int b = 1 + (lane >> 4);
+        const int qo = b == 1 ? Q_OFF1 : b == 2 ? Q_OFF2 : b == 3 ? Q_OFF3 : Q_OFF4;
+        s_qe[lane] = qres[lane];
+        s_qe[64 + lane] = qres[qo + (lane & 15)];
     }
-    if (tid < TW) {
-        const int64_t wd = (B >> 6) + tid;
-        if (wd < w.n_words) { w.tokmask[wd] = s_tm[tid]; w.blk_pre[wd] = (uint16_t)s_pre[tid]; }
+    wave_lds_fence();
+    uint32_t run = 0;
+    for (int k0 = 0; k0 < np; k0 += 512) {
+        if (k0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int k = k0 + j * 64 + lane; e[j] = (k < np) ? plist[k] : 0u; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (k0 + j * 64 >= np) break;
+            const int k = k0 + j * 64 + lane;
+            const uint32_t ej = e[j];
+            uint32_t c = (k < np) ? 1u : 0u;
+            uint64_t qe = 0;
+            const bool hard = (ej & JTK_PL_HARD) != 0;
+            const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
+            if (queued) {                                     // what the merge kernel left in the piece's queue entry
+                const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
+                if (bin == 0 && qi < 64u) qe = s_qe[qi];
+                else if (bin != 0 && qi < 16u) qe = s_qe[64 + (bin - 1) * 16 + qi];
+                else qe = qres[(bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : Q_OFF4) + qi];
+                c = (uint32_t)(qe >> JTK_QE_CNT_SHIFT) + 1u;
+            } else if (hard) c = hard_count(w, B + (ej & 2047u));         // wave / workgroup kernels: count in the htok header
+            // exclusive scan of c over the lanes.  c is 1 for most pieces and 2 or 3 for a few: count the lanes below
+            // and add the set bits of (c - 1) below, by ballots; a general scan only if some piece has more than 4 tokens
+            uint32_t pre;
+            {
+                const uint32_t x = c ? c - 1u : 0u;
+                const uint64_t valid = __ballot(c != 0u);
+                if (__ballot(x > 3u)) {
+                    const uint32_t inc = wave_incl_scan(c);
+                    pre = run + inc - c;
+                    run += (uint32_t)__shfl((int)inc, 63);
+                } else {
+                    const uint64_t b0 = __ballot((x & 1u) != 0u), b1 = __ballot((x & 2u) != 0u), lt = lanemask_lt();
+                    pre = run + (uint32_t)__popcll(valid & lt) + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt);
+                    run += (uint32_t)__popcll(valid) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);
+                }
+            }
+            uint32_t off = 0;
+            if (k < np) {
+                if (!hard) {
+                    off = (ej >> JTK_PL_OFF_SHIFT) & 2047u;
+                    dst[pre] = ej & JTK_HT_ID_MASK;
+                } else {
+                    off = ej & 2047u;
+                    if (queued && c <= 3) {
+                        dst[pre] = (uint32_t)qe & JTK_HT_ID_MASK;
+                        if (c > 1) dst[pre + 1] = (uint32_t)(qe >> 17) & JTK_HT_ID_MASK;
+                        if (c > 2) dst[pre + 2] = (uint32_t)(qe >> 34) & JTK_HT_ID_MASK;
+                    } else {
+                        const uint32_t* src = w.htok + B + off;
+                        for (uint32_t i = 0; i < c; i++) dst[pre + i] = src[i] & JTK_HT_ID_MASK;
+                    }
+                }
+            }
+            // document starts among these pieces: tokens of the tile before them
+            if (k < np && ((s_dm[off >> 6] >> (off & 63)) & 1ull)) w.docpre[B + off] = pre;
+        }
     }
 }
 
@@ -1069,9 +1185,8 @@ __global__ void __launch_bounds__(256) k_doc_offsets(JtkWork w) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > w.n_docs) return;
     const int64_t q = w.doc_off[d];
-    const int64_t wd = q >> 6;
-    const uint64_t m = w.tokmask[wd] & ((1ull << (q & 63)) - 1ull);
-    w.tok_off[d] = w.tile_off[q / T] + w.blk_pre[wd] + __popcll(m);
+    // a document starts a piece; documents at the very end (empty ones, and the end offset) start after the last token
+    w.tok_off[d] = (q >= w.n_bytes) ? w.tile_off[w.n_tiles] : w.tile_off[q / T] + w.docpre[q];
     if (d < w.n_docs) {
         const int32_t st = w.status[d];
         if (st < 0) atomicMin(&w.result->worst_status, st);
@@ -1101,14 +1216,16 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
 }
-void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
+void jtk_launch_bpe_merge16(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     const dim3 grid(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD);
     hipLaunchKernelGGL((k_bpe_merge<16, 1024, 0>), grid, dim3(1024), 0, s, w, t);
+}
+void jtk_launch_bpe_merge_bins(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
+    const dim3 grid(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD);
     hipLaunchKernelGGL((k_bpe_merge<32, 512, 1>), grid, dim3(512), 0, s, w, t);
     hipLaunchKernelGGL((k_bpe_merge<64, 256, 2>), grid, dim3(256), 0, s, w, t);
     hipLaunchKernelGGL((k_bpe_merge<128, 128, 3>), grid, dim3(128), 0, s, w, t);
     hipLaunchKernelGGL((k_bpe_merge<256, 64, 4>), grid, dim3(64), 0, s, w, t);
-    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 255) / 256)), dim3(256), 0, s, w);
 }
 void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_merge_long<JTK_MID_CAP>, dim3(2048), dim3(64), 0, s, w, t);
@@ -1118,11 +1235,10 @@ void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint
                                 uint32_t* scratch, hipStream_t s) {
     if (n_giant) hipLaunchKernelGGL(k_bpe_merge_giant, dim3(n_giant), dim3(256), 0, s, w, t, scratch_off, scratch);
 }
-void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, w);
-}
 void jtk_launch_pack(const JtkWork& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w);
+    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 63) / 64)), dim3(1024), 0, s, w);
+    hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((w.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK)), dim3(1024), 0, s, w);
+    hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)w.n_tiles), dim3(64), 0, s, w);
     const int64_t n = w.n_docs + 1;
     hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w);
 }

@@ -15,6 +15,11 @@ pass() {
   echo "pass $name done"
 }
 BENCH_ARGS="$*"
+if [ -n "$PMC_QUICK" ]; then   # PMC_QUICK=1: two passes only
+  pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
+  pass fetch FETCH_SIZE
+  exit 0
+fi
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
