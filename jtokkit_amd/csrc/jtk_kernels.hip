@@ -1089,6 +1089,22 @@ __device__ __forceinline__ uint32_t hard_count(const JtkWork& w, int64_t pos) {
     return 0;                                               // longer than JTK_GIANT_CAP: no tokens, status set
 }
 
+// c token ids from htok to the output, eight loads in flight per round trip (htok is padded by 16 words)
+struct __attribute__((packed, aligned(4))) U4Unaligned { uint32_t x, y, z, w; };
+__device__ __forceinline__ void pack_copy(uint32_t* dst, const uint32_t* src, uint32_t c) {
+    for (uint32_t i = 0; i < c; i += 8) {
+        const U4Unaligned a = *reinterpret_cast<const U4Unaligned*>(src + i), b = *reinterpret_cast<const U4Unaligned*>(src + i + 4);
+        dst[i] = a.x & JTK_HT_ID_MASK;
+        if (i + 1 < c) dst[i + 1] = a.y & JTK_HT_ID_MASK;
+        if (i + 2 < c) dst[i + 2] = a.z & JTK_HT_ID_MASK;
+        if (i + 3 < c) dst[i + 3] = a.w & JTK_HT_ID_MASK;
+        if (i + 4 < c) dst[i + 4] = b.x & JTK_HT_ID_MASK;
+        if (i + 5 < c) dst[i + 5] = b.y & JTK_HT_ID_MASK;
+        if (i + 6 < c) dst[i + 6] = b.z & JTK_HT_ID_MASK;
+        if (i + 7 < c) dst[i + 7] = b.w & JTK_HT_ID_MASK;
+    }
+}
+
 constexpr int PACK_QSTAGE = 128;               // queue entries of a tile staged in LDS (ordinary text: a few dozen)
 
 __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
@@ -1131,52 +1147,56 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             if (k0 + j * 64 >= np) break;
             const int k = k0 + j * 64 + lane;
             const uint32_t ej = e[j];
-            uint32_t c = (k < np) ? 1u : 0u;
-            uint64_t qe = 0;
+            const bool valid = k < np;
             const bool hard = (ej & JTK_PL_HARD) != 0;
-            const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
-            if (queued) {                                     // what the merge kernel left in the piece's queue entry
-                const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
-                if (bin == 0 && qi < 64u) qe = s_qe[qi];
-                else if (bin != 0 && qi < 16u) qe = s_qe[64 + (bin - 1) * 16 + qi];
-                else qe = qres[(bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : Q_OFF4) + qi];
-                c = (uint32_t)(qe >> JTK_QE_CNT_SHIFT) + 1u;
-            } else if (hard) c = hard_count(w, B + (ej & 2047u));         // wave / workgroup kernels: count in the htok header
-            // exclusive scan of c over the lanes.  c is 1 for most pieces and 2 or 3 for a few: count the lanes below
-            // and add the set bits of (c - 1) below, by ballots; a general scan only if some piece has more than 4 tokens
+            // The common case, written without divergent branches (the kernel is issue-bound): every merged piece among
+            // these 64 has its result in the staged head of the tile's slots and became at most 3 tokens.
+            const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
+            const bool staged = !(ej & JTK_PL_NOQUEUE) && (bin == 0 ? qi < 64u : qi < 16u);
+            const uint32_t sidx = (hard && staged) ? (bin == 0 ? qi : 48u + bin * 16u + qi) : 0u;
+            uint64_t qe = s_qe[sidx];
+            uint32_t c = valid ? (hard ? (uint32_t)(qe >> JTK_QE_CNT_SHIFT) + 1u : 1u) : 0u;
+            const uint32_t off = hard ? (ej & 2047u) : ((ej >> JTK_PL_OFF_SHIFT) & 2047u);
+            const bool isdoc = valid && ((s_dm[off >> 6] >> (off & 63)) & 1ull);
             uint32_t pre;
-            {
+            if (!__ballot(valid && hard && (!staged || c > 16u))) {
+                // exclusive scan of c (1 for most lanes, at most 16) by ballots of the bits of c - 1
                 const uint32_t x = c ? c - 1u : 0u;
-                const uint64_t valid = __ballot(c != 0u);
-                if (__ballot(x > 3u)) {
-                    const uint32_t inc = wave_incl_scan(c);
-                    pre = run + inc - c;
-                    run += (uint32_t)__shfl((int)inc, 63);
-                } else {
-                    const uint64_t b0 = __ballot((x & 1u) != 0u), b1 = __ballot((x & 2u) != 0u), lt = lanemask_lt();
-                    pre = run + (uint32_t)__popcll(valid & lt) + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt);
-                    run += (uint32_t)__popcll(valid) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);
+                const uint64_t bv = __ballot(valid), lt = lanemask_lt();
+                const uint64_t b0 = __ballot((x & 1u) != 0u), b1 = __ballot((x & 2u) != 0u), b2 = __ballot((x & 4u) != 0u), b3 = __ballot((x & 8u) != 0u);
+                pre = run + (uint32_t)__popcll(bv & lt) + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt);
+                run += (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);
+                if (b2 | b3) {
+                    pre += 4u * (uint32_t)__popcll(b2 & lt) + 8u * (uint32_t)__popcll(b3 & lt);
+                    run += 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
                 }
-            }
-            uint32_t off = 0;
-            if (k < np) {
-                if (!hard) {
-                    off = (ej >> JTK_PL_OFF_SHIFT) & 2047u;
-                    dst[pre] = ej & JTK_HT_ID_MASK;
-                } else {
-                    off = ej & 2047u;
-                    if (queued && c <= 3) {
+                if (valid && c <= 3u) dst[pre] = (hard ? (uint32_t)qe : ej) & JTK_HT_ID_MASK;
+                if (b0 | b1 | b2 | b3) {
+                    if (c == 2u || c == 3u) dst[pre + 1] = (uint32_t)(qe >> 17) & JTK_HT_ID_MASK;
+                    if (c == 3u) dst[pre + 2] = (uint32_t)(qe >> 34) & JTK_HT_ID_MASK;
+                    if (c > 3u) pack_copy(dst + pre, w.htok + B + off, c);
+                }
+            } else {
+                // general case: results beyond the staged head, very long results, wave / workgroup kernels
+                const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
+                if (valid && queued && !staged) {
+                    qe = qres[(bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : Q_OFF4) + qi];
+                    c = (uint32_t)(qe >> JTK_QE_CNT_SHIFT) + 1u;
+                } else if (valid && hard && !queued) c = hard_count(w, B + off);     // count in the htok header
+                const uint32_t inc = wave_incl_scan(c);
+                pre = run + inc - c;
+                run += (uint32_t)__shfl((int)inc, 63);
+                if (valid) {
+                    if (!hard) dst[pre] = ej & JTK_HT_ID_MASK;
+                    else if (queued && c <= 3) {
                         dst[pre] = (uint32_t)qe & JTK_HT_ID_MASK;
                         if (c > 1) dst[pre + 1] = (uint32_t)(qe >> 17) & JTK_HT_ID_MASK;
                         if (c > 2) dst[pre + 2] = (uint32_t)(qe >> 34) & JTK_HT_ID_MASK;
-                    } else {
-                        const uint32_t* src = w.htok + B + off;
-                        for (uint32_t i = 0; i < c; i++) dst[pre + i] = src[i] & JTK_HT_ID_MASK;
-                    }
+                    } else pack_copy(dst + pre, w.htok + B + off, c);
                 }
             }
             // document starts among these pieces: tokens of the tile before them
-            if (k < np && ((s_dm[off >> 6] >> (off & 63)) & 1ull)) w.docpre[B + off] = pre;
+            if (__ballot(isdoc)) { if (isdoc) w.docpre[B + off] = pre; }
         }
     }
 }
