@@ -278,7 +278,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
         (rc = b->plist.ensure(nt * JTK_TILE * 4)) || (rc = b->htok.ensure(nt * JTK_TILE * 4 + 64)) ||
         (rc = b->docpre.ensure(nt * JTK_TILE * 4)) ||
         (rc = b->tile_np.ensure(nt * 4 * 3)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
-        (rc = b->q_meta.ensure(nt * 4 * 16)) || (rc = b->qres.ensure(nt * (size_t)JTK_Q_PER_TILE * 8 + 1024)) ||
+        (rc = b->q_meta.ensure(nt * 4 * 16)) || (rc = b->qres.ensure(nt * (size_t)JTK_RES_PER_TILE * 16 + 1024)) ||
         (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 8)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||

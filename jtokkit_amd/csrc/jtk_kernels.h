@@ -13,14 +13,16 @@
 // Pieces that need bytePairMerge are queued by length bin; bin k holds pieces of up to JTK_BIN_SLOTS(k) bytes.
 // Queues are dense and sharded: tile t appends its entries to shard t % JTK_Q_SHARDS with one returning
 // atomic per tile and bin.  Entry: pos (37 bits) | (len - 1) << 37 (8 bits) | index in the tile's list of the bin << 45.
-// The merge kernel's result for a piece is one word: (token count - 1) << 56 | up to three token ids (17 bits each,
-// bits 0..50; a piece that became more than three tokens leaves them in htok).  It replaces the queue entry and is
-// also stored in the piece's result slot qres[tile][bin offset + index].
+// After the merge the entry holds (token count - 1) << 56 (summed per tile by k_tile_counts).
+// The merge RESULT of a piece is one 16-byte word in its slot qres[tile][bin offset + index]: (token count - 1) in the
+// top byte | up to seven token ids, 17 bits each from bit 0; a piece that became more than seven tokens, or whose index is
+// beyond the tile's slots of bin 0 (JTK_RES_CAP0), leaves its tokens in htok.
 #define JTK_QE_POS_MASK ((1ull << 37) - 1ull)
 #define JTK_QE_LEN_SHIFT 37
 #define JTK_QE_IDX_SHIFT 45
 #define JTK_QE_CNT_SHIFT 56
-#define JTK_Q_PER_TILE (JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4)
+#define JTK_RES_CAP0 256               // result slots of bin 0 per tile (a tile of ordinary text has a few dozen merged pieces)
+#define JTK_RES_PER_TILE (JTK_RES_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4)
 #define JTK_NBINS 5
 #define JTK_Q_SHARDS 64
 #define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
@@ -88,7 +90,7 @@ struct JtkWork {
     uint32_t* plist;        // [n_tiles * JTK_TILE] per tile, packed from the tile's first word: its pieces in text order,
                             // JTK_PL_* entry per piece (a piece belongs to the tile it starts in)
     uint32_t* tile_np;      // [n_tiles] pieces in each tile's list
-    uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece that became more than 3 tokens, packed from the
+    uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece without a (big enough) result slot, packed from the
                             // piece's first byte position (k <= len words); word 0 also carries the count k: id | k << 17
                             // (JTK_HT_ESCAPE: see giant_cnt)
     uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its tile before it (sparse)
@@ -100,7 +102,8 @@ struct JtkWork {
     uint64_t* q[JTK_NBINS];         // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k
     int64_t q_cap[JTK_NBINS];       // entries per shard
     uint32_t* q_count;              // [JTK_NBINS][JTK_Q_SHARDS]
-    uint64_t* qres;                 // [n_tiles][JTK_Q_PER_TILE] merge results at fixed slots (only the head of each tile's block is touched)
+    uint64_t* qres;                 // [n_tiles][JTK_RES_PER_TILE] x 16 bytes: merge results at fixed slots (only the head of each
+                                    // tile's block is touched)
     uint32_t* q_meta;               // [n_tiles][16]: [k] where in its shard the tile's entries of bin k start, [8 + k] how many
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces

@@ -362,6 +362,8 @@ __device__ __forceinline__ void piece_key(const uint8_t* tx, int s, int len, uin
     else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
 }
 
+constexpr int R_OFF0 = 0, R_OFF1 = JTK_RES_CAP0, R_OFF2 = R_OFF1 + JTK_BIN_CAP1, R_OFF3 = R_OFF2 + JTK_BIN_CAP2, R_OFF4 = R_OFF3 + JTK_BIN_CAP3;
+static_assert(R_OFF4 + JTK_BIN_CAP4 == JTK_RES_PER_TILE, "result slots per tile");
 constexpr int Q_OFF0 = 0, Q_OFF1 = JTK_BIN_CAP0, Q_OFF2 = Q_OFF1 + JTK_BIN_CAP1, Q_OFF3 = Q_OFF2 + JTK_BIN_CAP2,
               Q_OFF4 = Q_OFF3 + JTK_BIN_CAP3, Q_TOTAL = Q_OFF4 + JTK_BIN_CAP4;
 
@@ -751,47 +753,51 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
                 st = ST_MERGE;
             }
         }
-        // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The result --
-        // token count and, if the piece became at most 3 tokens (most do), the tokens -- is one 8-byte word; it goes
-        // to the piece's fixed result slot (tile, bin, index) for pack and replaces the queue entry for tile_counts.
-        // Longer results go to htok, packed from the piece's first byte position.
+        // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The result of a
+        // piece is ONE 16-byte word in its fixed result slot (tile, bin, index): count - 1 in the top byte and, if the
+        // piece became at most 7 tokens (nearly all do), the token ids, 17 bits each.  Longer results, and pieces beyond
+        // the tile's slots, leave their tokens in htok, packed from the piece's first byte position.  The count also
+        // replaces the queue entry, where k_tile_counts sums it.
         const uint64_t b_emit = __ballot(st == ST_EMIT);
         if (b_emit && (__popcll(b_emit) >= BATCH || !b_merge)) {
             if (st == ST_EMIT) {
                 uint32_t c = 0;
 #pragma unroll
                 for (int k = 0; k < NW; k++) c += (uint32_t)__popcll(alive[k]);
-                uint64_t ent = (uint64_t)(c - 1) << JTK_QE_CNT_SHIFT;
-                if (c <= 3) {
-                    const int j1 = mask_next_after<NW>(alive, 0);
-                    const int j2 = j1 >= 0 ? mask_next_after<NW>(alive, j1) : -1;
-                    ent |= (uint64_t)id[0];                                             // part 0 is never merged away
-                    if (j1 >= 0) ent |= (uint64_t)id[j1 * THREADS] << 17;
-                    if (j2 >= 0) ent |= (uint64_t)id[j2 * THREADS] << 34;
+                constexpr uint32_t RCAP = BIN == 0 ? JTK_RES_CAP0 : BIN == 1 ? JTK_BIN_CAP1 : BIN == 2 ? JTK_BIN_CAP2 : BIN == 3 ? JTK_BIN_CAP3 : JTK_BIN_CAP4;
+                constexpr int ROFF = BIN == 0 ? R_OFF0 : BIN == 1 ? R_OFF1 : BIN == 2 ? R_OFF2 : BIN == 3 ? R_OFF3 : R_OFF4;
+                const bool slotted = slot < RCAP;
+                uint64_t lo = 0, hi = (uint64_t)(c - 1) << 56;
+                if (slotted && c <= 7) {
+                    uint32_t sh = 0;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        for (uint64_t m = alive[k]; m;) {
+                            const int j = k * 64 + jtk_ctz64(m);
+                            m &= m - 1;
+                            const uint64_t v = id[j * THREADS];
+                            if (sh < 64u) lo |= v << sh;
+                            if (sh > 47u) hi |= sh < 64u ? v >> (64u - sh) : v << (sh - 64u);
+                            sh += 17u;
+                        }
+                    }
                 } else {
                     uint32_t* dst = w.htok + pos;
-                    dst[0] = id[0] | (c << JTK_HT_CNT_SHIFT);
-                    if (SLOTS <= 16) {
-                        uint32_t idx = 1;
+                    dst[0] = id[0] | (c << JTK_HT_CNT_SHIFT);                    // part 0 is never merged away
+                    uint32_t idx = 0;
 #pragma unroll
-                        for (int j = 1; j < SLOTS; j++) {
-                            if ((alive[0] >> j) & 1ull) { dst[idx] = id[j * THREADS]; idx++; }
-                        }
-                    } else {
-                        uint32_t idx = 0;
-#pragma unroll
-                        for (int k = 0; k < NW; k++) {
-                            for (uint64_t m = alive[k] & ~(uint64_t)(k == 0); m;) {
-                                const int j = k * 64 + jtk_ctz64(m);
-                                m &= m - 1;
-                                dst[++idx] = id[j * THREADS];
-                            }
+                    for (int k = 0; k < NW; k++) {
+                        for (uint64_t m = alive[k] & ~(uint64_t)(k == 0); m;) {
+                            const int j = k * 64 + jtk_ctz64(m);
+                            m &= m - 1;
+                            dst[++idx] = id[j * THREADS];
                         }
                     }
                 }
-                constexpr int QOFF = BIN == 0 ? Q_OFF0 : BIN == 1 ? Q_OFF1 : BIN == 2 ? Q_OFF2 : BIN == 3 ? Q_OFF3 : Q_OFF4;
-                w.qres[(pos / T) * Q_TOTAL + QOFF + slot] = ent;       // where pack finds it without an indirection
-                queue[qi] = ent;                                       // dense: k_tile_counts sums the counts
+                if (slotted)
+                    reinterpret_cast<uint4*>(w.qres)[(pos / T) * JTK_RES_PER_TILE + ROFF + slot] =
+                        make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                queue[qi] = (uint64_t)(c - 1) << JTK_QE_CNT_SHIFT;                // dense: k_tile_counts sums the counts
                 st = ST_NEED;
             }
         }
@@ -1105,18 +1111,30 @@ __device__ __forceinline__ void pack_copy(uint32_t* dst, const uint32_t* src, ui
     }
 }
 
-constexpr int PACK_QSTAGE = 128;               // queue entries of a tile staged in LDS (ordinary text: a few dozen)
+// token I (0..6) of a 16-byte merge result: 17 bits at bit 17 * I
+template <int I> __device__ __forceinline__ uint32_t res_tok(const uint4& r) {
+    constexpr int bit = 17 * I, wd = bit / 32, sh = bit % 32;
+    const uint32_t w0 = wd == 0 ? r.x : wd == 1 ? r.y : wd == 2 ? r.z : r.w;
+    const uint32_t w1 = wd == 0 ? r.y : wd == 1 ? r.z : r.w;
+    return (sh + 17 <= 32 ? (w0 >> sh) : __builtin_amdgcn_alignbit(w1, w0, sh)) & JTK_HT_ID_MASK;
+}
+
+constexpr int PACK_STAGE = 1024;               // tokens of a tile assembled in LDS (ordinary text: a few hundred)
 
 __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
-    // ONE WAVE PER TILE.  The kernel is bound by the latency of dependent HBM reads at a fixed number of resident
-    // waves, so a wave keeps a whole tile in flight: 8 list entries per lane, the head of the tile's merge results
-    // (LDS) and the document mask are all requested before the first wait.  No workgroup barriers.
-    __shared__ uint64_t s_qe[PACK_QSTAGE];
+    // ONE WAVE PER TILE, no workgroup barriers.  A wave keeps a whole tile in flight: 8 list entries per lane, the head
+    // of the tile's merge results and the document mask are all requested before the first wait.  The tile's tokens are
+    // assembled in LDS (the few multi-token pieces make sparse writes, cheap there and expensive in memory) and leave
+    // in full 256-byte stores.
+    __shared__ uint4 s_qe[128];
     __shared__ uint64_t s_dm[TW];
+    __shared__ uint32_t s_out[PACK_STAGE];
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t B = tile * T;
     const int np = (int)w.tile_np[tile];
+    const uint32_t total = w.tile_tot[tile];
+    const bool stage = total <= (uint32_t)PACK_STAGE;
     const uint32_t* plist = w.plist + B;
     uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens + w.tile_off[tile]);
     uint32_t e[8];
@@ -1128,15 +1146,76 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     }
     // the head of the tile's result slots, read speculatively (no dependence on the list): the first 64 of bin 0
     // and the first 16 of bins 1..4; slots beyond are read on demand
-    const uint64_t* qres = w.qres + tile * Q_TOTAL;
+    const uint4* qres = reinterpret_cast<const uint4*>(w.qres) + tile * JTK_RES_PER_TILE;
     {
         const int b = 1 + (lane >> 4);
-        const int qo = b == 1 ? Q_OFF1 : b == 2 ? Q_OFF2 : b == 3 ? Q_OFF3 : Q_OFF4;
+        const int ro = b == 1 ? R_OFF1 : b == 2 ? R_OFF2 : b == 3 ? R_OFF3 : R_OFF4;
         s_qe[lane] = qres[lane];
-        s_qe[64 + lane] = qres[qo + (lane & 15)];
+        s_qe[64 + lane] = qres[ro + (lane & 15)];
     }
     wave_lds_fence();
     uint32_t run = 0;
+    // one step: 64 consecutive pieces of the list, entry ej in lane order; out = s_out or dst
+    auto step = [&](uint32_t* out, uint32_t ej, int k) {
+        const bool valid = k < np;
+        const bool hard = (ej & JTK_PL_HARD) != 0;
+        const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
+        const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
+        const bool slotted = queued && (bin != 0 || qi < (uint32_t)JTK_RES_CAP0);
+        const bool staged = slotted && (bin == 0 ? qi < 64u : qi < 16u);
+        const uint32_t sidx = staged ? (bin == 0 ? qi : 48u + bin * 16u + qi) : 0u;
+        uint4 qe = s_qe[sidx];
+        uint32_t c = valid ? (hard ? (qe.w >> 24) + 1u : 1u) : 0u;
+        const uint32_t off = hard ? (ej & 2047u) : ((ej >> JTK_PL_OFF_SHIFT) & 2047u);
+        const bool isdoc = valid && ((s_dm[off >> 6] >> (off & 63)) & 1ull);
+        uint32_t pre;
+        if (!__ballot(valid && hard && (!staged || c > 7u))) {
+            // the common case, without divergent branches: exclusive scan of c (1 for most lanes, at most 7) by ballots of
+            // the bits of c - 1, first tokens in one full store, the few further ones in sparse stores
+            const uint32_t x = c ? c - 1u : 0u;
+            const uint64_t bv = __ballot(valid), lt = lanemask_lt();
+            const uint64_t b0 = __ballot((x & 1u) != 0u), b1 = __ballot((x & 2u) != 0u), b2 = __ballot((x & 4u) != 0u);
+            pre = run + (uint32_t)__popcll(bv & lt) + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
+            run += (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+            if (valid) out[pre] = (hard ? qe.x : ej) & JTK_HT_ID_MASK;
+            if (b0 | b1 | b2) {
+                if (c > 1u) out[pre + 1] = res_tok<1>(qe);
+                if (c > 2u) out[pre + 2] = res_tok<2>(qe);
+                if (b1 | b2) {
+                    if (c > 3u) out[pre + 3] = res_tok<3>(qe);
+                    if (b2) {
+                        if (c > 4u) out[pre + 4] = res_tok<4>(qe);
+                        if (c > 5u) out[pre + 5] = res_tok<5>(qe);
+                        if (c > 6u) out[pre + 6] = res_tok<6>(qe);
+                    }
+                }
+            }
+        } else {
+            // general case: results beyond the staged head or beyond the tile's slots, results of more than 7 tokens,
+            // pieces merged by the wave / workgroup kernels (htok)
+            if (valid && slotted && !staged) {
+                qe = qres[(bin == 0 ? R_OFF0 : bin == 1 ? R_OFF1 : bin == 2 ? R_OFF2 : bin == 3 ? R_OFF3 : R_OFF4) + qi];
+                c = (qe.w >> 24) + 1u;
+            } else if (valid && hard && !slotted) c = hard_count(w, B + off);       // count in the htok header
+            const uint32_t inc = wave_incl_scan(c);
+            pre = run + inc - c;
+            run += (uint32_t)__shfl((int)inc, 63);
+            if (valid) {
+                if (!hard) out[pre] = ej & JTK_HT_ID_MASK;
+                else if (slotted && c <= 7u) {
+                    out[pre] = qe.x & JTK_HT_ID_MASK;
+                    if (c > 1u) out[pre + 1] = res_tok<1>(qe);
+                    if (c > 2u) out[pre + 2] = res_tok<2>(qe);
+                    if (c > 3u) out[pre + 3] = res_tok<3>(qe);
+                    if (c > 4u) out[pre + 4] = res_tok<4>(qe);
+                    if (c > 5u) out[pre + 5] = res_tok<5>(qe);
+                    if (c > 6u) out[pre + 6] = res_tok<6>(qe);
+                } else pack_copy(out + pre, w.htok + B + off, c);
+            }
+        }
+        // document starts among these pieces: tokens of the tile before them
+        if (__ballot(isdoc)) { if (isdoc) w.docpre[B + off] = pre; }
+    };
     for (int k0 = 0; k0 < np; k0 += 512) {
         if (k0) {
 #pragma unroll
@@ -1145,59 +1224,13 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (k0 + j * 64 >= np) break;
-            const int k = k0 + j * 64 + lane;
-            const uint32_t ej = e[j];
-            const bool valid = k < np;
-            const bool hard = (ej & JTK_PL_HARD) != 0;
-            // The common case, written without divergent branches (the kernel is issue-bound): every merged piece among
-            // these 64 has its result in the staged head of the tile's slots and became at most 3 tokens.
-            const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
-            const bool staged = !(ej & JTK_PL_NOQUEUE) && (bin == 0 ? qi < 64u : qi < 16u);
-            const uint32_t sidx = (hard && staged) ? (bin == 0 ? qi : 48u + bin * 16u + qi) : 0u;
-            uint64_t qe = s_qe[sidx];
-            uint32_t c = valid ? (hard ? (uint32_t)(qe >> JTK_QE_CNT_SHIFT) + 1u : 1u) : 0u;
-            const uint32_t off = hard ? (ej & 2047u) : ((ej >> JTK_PL_OFF_SHIFT) & 2047u);
-            const bool isdoc = valid && ((s_dm[off >> 6] >> (off & 63)) & 1ull);
-            uint32_t pre;
-            if (!__ballot(valid && hard && (!staged || c > 16u))) {
-                // exclusive scan of c (1 for most lanes, at most 16) by ballots of the bits of c - 1
-                const uint32_t x = c ? c - 1u : 0u;
-                const uint64_t bv = __ballot(valid), lt = lanemask_lt();
-                const uint64_t b0 = __ballot((x & 1u) != 0u), b1 = __ballot((x & 2u) != 0u), b2 = __ballot((x & 4u) != 0u), b3 = __ballot((x & 8u) != 0u);
-                pre = run + (uint32_t)__popcll(bv & lt) + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt);
-                run += (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);
-                if (b2 | b3) {
-                    pre += 4u * (uint32_t)__popcll(b2 & lt) + 8u * (uint32_t)__popcll(b3 & lt);
-                    run += 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
-                }
-                if (valid && c <= 3u) dst[pre] = (hard ? (uint32_t)qe : ej) & JTK_HT_ID_MASK;
-                if (b0 | b1 | b2 | b3) {
-                    if (c == 2u || c == 3u) dst[pre + 1] = (uint32_t)(qe >> 17) & JTK_HT_ID_MASK;
-                    if (c == 3u) dst[pre + 2] = (uint32_t)(qe >> 34) & JTK_HT_ID_MASK;
-                    if (c > 3u) pack_copy(dst + pre, w.htok + B + off, c);
-                }
-            } else {
-                // general case: results beyond the staged head, very long results, wave / workgroup kernels
-                const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
-                if (valid && queued && !staged) {
-                    qe = qres[(bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : Q_OFF4) + qi];
-                    c = (uint32_t)(qe >> JTK_QE_CNT_SHIFT) + 1u;
-                } else if (valid && hard && !queued) c = hard_count(w, B + off);     // count in the htok header
-                const uint32_t inc = wave_incl_scan(c);
-                pre = run + inc - c;
-                run += (uint32_t)__shfl((int)inc, 63);
-                if (valid) {
-                    if (!hard) dst[pre] = ej & JTK_HT_ID_MASK;
-                    else if (queued && c <= 3) {
-                        dst[pre] = (uint32_t)qe & JTK_HT_ID_MASK;
-                        if (c > 1) dst[pre + 1] = (uint32_t)(qe >> 17) & JTK_HT_ID_MASK;
-                        if (c > 2) dst[pre + 2] = (uint32_t)(qe >> 34) & JTK_HT_ID_MASK;
-                    } else pack_copy(dst + pre, w.htok + B + off, c);
-                }
-            }
-            // document starts among these pieces: tokens of the tile before them
-            if (__ballot(isdoc)) { if (isdoc) w.docpre[B + off] = pre; }
+            if (stage) step(s_out, e[j], k0 + j * 64 + lane);
+            else step(dst, e[j], k0 + j * 64 + lane);
         }
+    }
+    if (stage) {
+        wave_lds_fence();
+        for (uint32_t i = lane; i < total; i += WAVE) dst[i] = s_out[i];
     }
 }
 
