@@ -63,6 +63,11 @@ def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16):
     }
 
 
+# stage (HIP-event bracket in jtk_batch_kernel_times) -> the kernel it launches, as rocprofv3 names it
+STAGE_KERNEL = {"bpe_merge16": "k_bpe_merge<16, 1024, 0>", "piece_resolve": "k_piece_resolve",
+                "pretok_split": "k_pretok_split<1>", "mark_docs": "k_mark_docs", "special_check": "k_special_check"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +153,16 @@ def main():
         for k in stage_ms:
             stage_ms[k] /= steps
         dom = max(stage_ms, key=stage_ms.get)
+        dom_kernel = STAGE_KERNEL.get(dom, dom)
+        # HBM bytes of one launch of that kernel from the committed PMC passes (same workload only)
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            if pt.get("workload") == wl and dom_kernel in pt["kernels"]:
+                k = pt["kernels"][dom_kernel]
+                traffic = int((k["hbm_read_MB"] + k["hbm_write_MB"]) * 1e6)
+        except (OSError, ValueError, KeyError):
+            traffic = None
         # algorithmic bytes of one batch: input once + int32 tokens once + both offset arrays
         bytes_alg = n_bytes + 4 * nt + 16 * (n_docs + 1)
         achieved = bytes_alg / (stage_ms[dom] * 1e-3) / 1e9
@@ -161,8 +176,8 @@ def main():
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": wl, "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes, "tokens_per_gpu": int(nt),
                        "sharding": "contiguous doc shards, one per GPU" + ("; RCCL all-gather of shard token totals" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_alg),
                          "avg_launch_ms": round(stage_ms[dom], 4)},
             "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()},
