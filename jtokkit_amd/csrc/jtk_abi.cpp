@@ -71,7 +71,7 @@ struct jtk_batch {
     JtkWork work{};
     bool have_result = false, synced = false;
     bool profiling = false;
-    hipEvent_t ev[N_STAGES + 1] = {};
+    hipEvent_t ev0[N_STAGES] = {}, ev1[N_STAGES] = {};   // start / end of each stage, on the stream it runs on
     bool ev_ok = false, ev_recorded = false;
 };
 
@@ -226,7 +226,7 @@ void jtk_batch_destroy(jtk_batch* b) {
                       &b->giant_list, &b->giant_off, &b->giant_scratch,
                       &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
-    if (b->ev_ok) for (auto& ev : b->ev) (void)hipEventDestroy(ev);
+    if (b->ev_ok) { for (auto& ev : b->ev0) (void)hipEventDestroy(ev); for (auto& ev : b->ev1) (void)hipEventDestroy(ev); }
     if (b->host_result) (void)hipHostFree(b->host_result);
     (void)hipStreamDestroy(b->stream);
     delete b;
@@ -236,7 +236,8 @@ int jtk_batch_set_profiling(jtk_batch* b, int enabled) {
     if (!b) return fail(JTK_ERR_INVALID_ARGUMENT, "batch is NULL");
     HIP_TRY(hipSetDevice(b->enc->device));
     if (enabled && !b->ev_ok) {
-        for (auto& ev : b->ev) HIP_TRY(hipEventCreate(&ev));
+        for (auto& ev : b->ev0) HIP_TRY(hipEventCreate(&ev));
+        for (auto& ev : b->ev1) HIP_TRY(hipEventCreate(&ev));
         b->ev_ok = true;
     }
     b->profiling = enabled != 0;
@@ -323,28 +324,38 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.tok_off = (int64_t*)b->tok_off.p;
 
     const bool prof = b->profiling && b->ev_ok;
-    int evi = 0;
-    auto mark = [&]() { if (prof) (void)hipEventRecord(b->ev[evi++], s); };
+    int stage = 0;
+    auto begin = [&](hipStream_t st) { if (prof) (void)hipEventRecord(b->ev0[stage], st); };
+    auto end = [&](hipStream_t st) { if (prof) (void)hipEventRecord(b->ev1[stage], st); stage++; };
 
-    mark();
+    begin(s);                                                   // mark_docs
     HIP_TRY(hipMemsetAsync(b->zeroed.p, 0, zero_bytes, s));
     jtk_launch_mark_docs(w, s);
-    mark();
+    end(s);
+    begin(s);                                                   // special_check (+ utf8 validation)
     if (!(flags & JTK_ENCODE_ORDINARY)) jtk_launch_special_check(w, enc->dt, s);
     if (flags & JTK_ENCODE_VALIDATE_UTF8) jtk_launch_validate_utf8(w, s);
-    mark();
+    end(s);
+    begin(s);
     jtk_launch_pretok_split(w, enc->dt, s);
-    mark();
+    end(s);
+    begin(s);
     jtk_launch_piece_resolve(w, enc->dt, s);
-    mark();
+    end(s);
+    // (running the kernels for longer pieces on a second stream under k_bpe_merge<16> was tried: every merge
+    // workgroup needs a whole CU's LDS, so they serialise anyway)
+    begin(s);
     jtk_launch_bpe_merge16(w, enc->dt, s);
-    mark();
+    end(s);
+    begin(s);
     jtk_launch_bpe_merge_bins(w, enc->dt, s);
-    mark();
+    end(s);
+    begin(s);
     jtk_launch_bpe_merge_long(w, enc->dt, s);
-    mark();
+    end(s);
+    begin(s);
     jtk_launch_pack(w, s);
-    mark();
+    end(s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->host_result, w.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
     b->have_result = true;
@@ -421,10 +432,10 @@ int jtk_batch_kernel_times(jtk_batch* b, const char** names, float* ms, int cap,
     *n = 0;
     if (!b->ev_recorded) return fail(JTK_ERR_INVALID_ARGUMENT, "profiling was not enabled for the last encode");
     HIP_TRY(hipSetDevice(b->enc->device));
-    HIP_TRY(hipEventSynchronize(b->ev[N_STAGES]));
+    HIP_TRY(hipEventSynchronize(b->ev1[N_STAGES - 1]));
     for (int i = 0; i < N_STAGES && i < cap; i++) {
         float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, b->ev[i], b->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t, b->ev0[i], b->ev1[i]));
         if (names) names[i] = STAGE_NAMES[i];
         if (ms) ms[i] = t;
         *n = i + 1;

@@ -247,19 +247,8 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
         if (p0 + 63 >= n) ds |= (p0 >= n) ? ~0ull : ~((1ull << (n - p0)) - 1ull);
         cu.DS = ds;
     }
-    // bytes that cannot share a part with the byte before them (see the piecemask store below)
-    uint64_t cut = 0;
-    {
-        uint32_t prev = (uint32_t)__shfl_up((int)(d[15] >> 24), 1);
-        if (lane == 0) prev = (p0 > 0 && p0 <= n) ? w.text[p0 - 1] : 0u;
-#pragma unroll
-        for (int j = 0; j < 64; j++) {
-            const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 255u;
-            const uint32_t pi = (prev << 8) | cur;
-            cut |= (uint64_t)(((s_pin[pi >> 5] >> (pi & 31u)) & 1u) ^ 1u) << j;
-            prev = cur;
-        }
-    }
+    uint32_t prev_byte = (uint32_t)__shfl_up((int)(d[15] >> 24), 1);          // the byte before this block
+    if (lane == 0) prev_byte = (p0 > 0 && p0 <= n) ? w.text[p0 - 1] : 0u;
 
     // ---- the split rules for the whole block
     JtkBlk nx;
@@ -316,14 +305,27 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
         ms = v ? (ms | (1ull << j)) : (ms & ~(1ull << j));
     }
 
+    // Extra cuts inside regex pieces: where two bytes never occur next to each other inside any table entry no
+    // merge can cross (every part is a table entry), so bytePairMerge of the piece equals the concatenation of
+    // bytePairMerge of the two sides.  Long CJK runs fall apart into a few bytes each.  Any subset of these cuts
+    // is exact, so blocks of short ASCII pieces (ordinary text) skip the 64 bitmap lookups.
+    uint64_t cut = 0;
+    if ((lead | cu.CONT) != 0 || __popcll(ms) < 6) {
+        uint32_t prev = prev_byte;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 255u;
+            const uint32_t pi = (prev << 8) | cur;
+            cut |= (uint64_t)(((s_pin[pi >> 5] >> (pi & 31u)) & 1u) ^ 1u) << j;
+            prev = cur;
+        }
+    }
+
     if (lane >= 1 && lane <= SPW) {
         uint64_t valid = 0;                                           // positions <= n
         if (p0 + 63 <= n) valid = ~0ull;
         else if (p0 <= n) valid = (2ull << (n - p0)) - 1ull;
         const int64_t wd = p0 >> 6;
-        // Extra cuts inside regex pieces: where two bytes never occur next to each other inside any table
-        // entry no merge can cross (every part is a table entry), so bytePairMerge of the piece equals
-        // the concatenation of bytePairMerge of the two sides.  Long CJK runs fall apart into a few bytes each.
         if (wd < w.n_words) w.piecemask[wd] = (ms | cut) & valid;
     }
 }
