@@ -134,6 +134,21 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
  * byte strings of `ids`; *len receives the byte count (out may be NULL to size). */
 int jtk_decode(const jtk_encoding* enc, const int32_t* ids, int64_t n, uint8_t* out, int64_t cap, int64_t* len);
 
+/* ---- batch decode on the device ---------------------------------------------------------------------
+ * Replaces a loop of Encoding.decodeBytes(List<Integer>) (GptBytePairEncoding.java:137-151, 302-314; special-token
+ * ids decode to their literals, :308-311) over n_seqs token lists: all ids back to back in `ids`, list q occupying
+ * [seq_off[q], seq_off[q+1]).  Result: the byte strings back to back, list q occupying [byte_off[q], byte_off[q+1]);
+ * status[q] = JTK_OK or JTK_ERR_UNKNOWN_TOKEN (that list's bytes then omit the unknown ids).  Both calls synchronise
+ * and leave the result on the device; *n_bytes receives the total byte count. */
+int jtk_batch_decode(jtk_batch* b, const int32_t* ids, const int64_t* seq_off, int64_t n_seqs, int64_t* n_bytes);
+int jtk_batch_decode_device(jtk_batch* b, const int32_t* d_ids, const int64_t* d_seq_off, int64_t n_seqs, int64_t n_ids,
+                            void* stream_or_null, int64_t* n_bytes);
+/* Copies the last decode to host buffers: out[out_cap] (JTK_ERR_CAPACITY if too small), byte_off[n_seqs + 1],
+ * status[n_seqs]; any may be NULL. */
+int jtk_batch_decode_fetch(jtk_batch* b, uint8_t* out, int64_t out_cap, int64_t* byte_off, int32_t* status);
+/* Device pointers of the last decode (valid until the next decode on this batch). */
+int jtk_batch_decode_device_result(jtk_batch* b, const uint8_t** d_out, const int64_t** d_byte_off, const int32_t** d_status);
+
 #define JTK_MAX_PIECE_BYTES (1 << 20)
 
 #ifdef __cplusplus

@@ -53,7 +53,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct jtk_encoding {
     JtkHostTables host;
     int device = 0;
-    DevBuf uc1, uc2, brank, pairs, tok8, bprank, bpbits, bpcum, bpranks, pairin;
+    DevBuf uc1, uc2, brank, pairs, tok8, bprank, bpbits, bpcum, bpranks, pairin, dec_off, dec_blob;
+    uint32_t n_ids_table = 0;        // ids 0 .. n_ids_table-1 have an entry in the decode table (incl. special tokens)
     JtkDeviceTables dt;
     std::vector<uint32_t> tok_len;   // byte length per id (0 = absent), for the maxTokens back-off
 };
@@ -66,11 +67,18 @@ struct jtk_batch {
     DevBuf zeroed;                   // docmask | status | result | list counters | queue counters | pack scan state
     DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, qres, q_meta, mid_list, long_list,
         giant_list, giant_cnt, giant_off, giant_scratch, tokens, tok_off;
+    // batch decode (jtk_batch_decode*)
+    DevBuf dec_in_ids, dec_in_off, dec_zero, dec_tile, dec_pre, dec_out, dec_byte_off;
+    JtkDecodeWork dwork{};
+    bool have_decode = false;
+    int64_t dec_total = 0;
     bool giants_pending = false;
     JtkResult* host_result = nullptr;   // pinned
     JtkWork work{};
     bool have_result = false, synced = false;
     bool profiling = false;
+    hipStream_t side = nullptr;          // the kernels for pieces of more than 16 bytes are launched here
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0[N_STAGES] = {}, ev1[N_STAGES] = {};   // start / end of each stage, on the stream it runs on
     bool ev_ok = false, ev_recorded = false;
 };
@@ -144,7 +152,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     }
     if (device < 0 || device >= ndev) { delete enc; return fail(JTK_ERR_INVALID_ARGUMENT, "device index out of range"); }
     enc->device = device;
-    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); delete enc; };
+    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); delete enc; };
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(JTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     ENC_TRY(hipSetDevice(device));
     if (enc->uc1.ensure(sizeof(jtk_uc_stage1_init)) || enc->uc2.ensure(sizeof(jtk_uc_stage2_init)) ||
@@ -161,6 +169,22 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     ENC_TRY(hipMemcpy(enc->bpcum.p, enc->host.bp_cum.data(), 1024 * 2, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bpranks.p, enc->host.bp_ranks.data(), JTK_BP_MAX * 4, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->pairin.p, enc->host.pair_in_token.data(), 2048 * 4, hipMemcpyHostToDevice));
+    {   // decode table: byte strings of all ids (rank table + special tokens, GptBytePairEncoding.java:302-314) back to back
+        uint32_t n_ids = enc->host.max_id + 1;
+        for (auto& sp : enc->host.specials) if (sp.second >= 0 && (uint32_t)sp.second + 1 > n_ids) n_ids = (uint32_t)sp.second + 1;
+        std::vector<const std::string*> str(n_ids, nullptr);
+        for (uint32_t i = 0; i <= enc->host.max_id; i++) if (enc->host.id_present[i]) str[i] = &enc->host.id_to_bytes[i];
+        for (auto& sp : enc->host.specials) if (sp.second >= 0 && !str[(size_t)sp.second]) str[(size_t)sp.second] = &sp.first;
+        std::vector<uint32_t> off(n_ids + 1, 0);
+        std::string blob;
+        for (uint32_t i = 0; i < n_ids; i++) { off[i] = (uint32_t)blob.size(); if (str[i]) blob += *str[i]; }
+        off[n_ids] = (uint32_t)blob.size();
+        blob.append(16, '\0');
+        if (enc->dec_off.ensure(off.size() * 4) || enc->dec_blob.ensure(blob.size())) { cleanup(); return JTK_ERR_OUT_OF_MEMORY; }
+        ENC_TRY(hipMemcpy(enc->dec_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+        ENC_TRY(hipMemcpy(enc->dec_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        enc->n_ids_table = n_ids;
+    }
 #undef ENC_TRY
     JtkDeviceTables& dt = enc->dt;
     memset(&dt, 0, sizeof(dt));
@@ -207,8 +231,14 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
     if (!b) return fail(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
     b->enc = enc;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result, sizeof(JtkResult), hipHostMallocDefault);
     if (e != hipSuccess) {
+        if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+        if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+        if (b->side) (void)hipStreamDestroy(b->side);
         if (b->stream) (void)hipStreamDestroy(b->stream);
         delete b;
         return fail(JTK_ERR_HIP, std::string("batch create: ") + hipGetErrorString(e));
@@ -223,11 +253,16 @@ void jtk_batch_destroy(jtk_batch* b) {
     (void)hipStreamSynchronize(b->stream);
     DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->plist, &b->htok, &b->docpre,
                       &b->tile_np, &b->tile_off, &b->queues, &b->qres, &b->q_meta, &b->giant_cnt, &b->mid_list, &b->long_list,
-                      &b->giant_list, &b->giant_off, &b->giant_scratch,
+                      &b->giant_list, &b->giant_off, &b->giant_scratch, &b->dec_in_ids, &b->dec_in_off, &b->dec_zero,
+                      &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off,
                       &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
     if (b->ev_ok) { for (auto& ev : b->ev0) (void)hipEventDestroy(ev); for (auto& ev : b->ev1) (void)hipEventDestroy(ev); }
     if (b->host_result) (void)hipHostFree(b->host_result);
+    (void)hipEventDestroy(b->ev_fork);
+    (void)hipEventDestroy(b->ev_join);
+    (void)hipStreamSynchronize(b->side);
+    (void)hipStreamDestroy(b->side);
     (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -342,17 +377,23 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     begin(s);
     jtk_launch_piece_resolve(w, enc->dt, s);
     end(s);
-    // (running the kernels for longer pieces on a second stream under k_bpe_merge<16> was tried: every merge
-    // workgroup needs a whole CU's LDS, so they serialise anyway)
+    // fork: the kernels for pieces of more than 16 bytes are launched on a side stream.  Every merge workgroup
+    // needs a whole CU's LDS, so their work does not overlap with k_bpe_merge<16>, but on ordinary text they are
+    // six nearly empty launches whose launch latencies now hide under it (3 % of the step at cfg 2).
+    hipStream_t sd = b->side;
+    HIP_TRY(hipEventRecord(b->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(sd, b->ev_fork, 0));
     begin(s);
     jtk_launch_bpe_merge16(w, enc->dt, s);
     end(s);
-    begin(s);
-    jtk_launch_bpe_merge_bins(w, enc->dt, s);
-    end(s);
-    begin(s);
-    jtk_launch_bpe_merge_long(w, enc->dt, s);
-    end(s);
+    begin(sd);
+    jtk_launch_bpe_merge_bins(w, enc->dt, sd);
+    end(sd);
+    begin(sd);
+    jtk_launch_bpe_merge_long(w, enc->dt, sd);
+    end(sd);
+    HIP_TRY(hipEventRecord(b->ev_join, sd));
+    HIP_TRY(hipStreamWaitEvent(s, b->ev_join, 0));
     begin(s);
     jtk_launch_pack(w, s);
     end(s);
@@ -440,6 +481,89 @@ int jtk_batch_kernel_times(jtk_batch* b, const char** names, float* ms, int cap,
         if (ms) ms[i] = t;
         *n = i + 1;
     }
+    return JTK_OK;
+}
+
+// ---- batch decode ------------------------------------------------------------------------------------
+int jtk_batch_decode_device(jtk_batch* b, const int32_t* d_ids, const int64_t* d_seq_off, int64_t n_seqs, int64_t n_ids,
+                            void* stream_or_null, int64_t* n_bytes) {
+    if (!b || n_seqs < 0 || n_ids < 0 || (n_ids > 0 && !d_ids) || !d_seq_off) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    const jtk_encoding* enc = b->enc;
+    HIP_TRY(hipSetDevice(enc->device));
+    hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : b->stream;
+    JtkDecodeWork& w = b->dwork;
+    w.ids = d_ids; w.seq_off = d_seq_off; w.n_tok = n_ids; w.n_seqs = n_seqs;
+    w.n_tiles = (n_ids + JTK_DEC_TILE - 1) / JTK_DEC_TILE;
+    if (w.n_tiles < 1) w.n_tiles = 1;
+    w.tab_off = (const uint32_t*)enc->dec_off.p; w.tab_blob = (const uint8_t*)enc->dec_blob.p; w.n_ids_table = enc->n_ids_table;
+    const size_t nt = (size_t)w.n_tiles;
+    const size_t mask_bytes = (nt * (JTK_DEC_TILE / 64) + 2) * 8;
+    const size_t status_bytes = align_up((size_t)(n_seqs > 0 ? n_seqs : 1) * 4, 16);
+    const size_t zero_bytes = mask_bytes + status_bytes + 16;
+    int rc;
+    if ((rc = b->dec_zero.ensure(zero_bytes)) || (rc = b->dec_tile.ensure(nt * 4 + (nt + 1) * 8 + 16)) ||
+        (rc = b->dec_pre.ensure(nt * JTK_DEC_TILE * 4)) || (rc = b->dec_byte_off.ensure(((size_t)n_seqs + 1) * 8)))
+        return rc;
+    uint8_t* z = (uint8_t*)b->dec_zero.p;
+    w.seqmask = (uint64_t*)z;
+    w.status = (int32_t*)(z + mask_bytes);
+    w.total = (int64_t*)(z + mask_bytes + status_bytes);
+    w.worst_status = (int32_t*)(z + mask_bytes + status_bytes + 8);
+    w.tile_off = (int64_t*)b->dec_tile.p;
+    w.tile_bytes = (uint32_t*)((uint8_t*)b->dec_tile.p + (nt + 1) * 8);
+    w.seqpre = (uint32_t*)b->dec_pre.p;
+    w.byte_off = (int64_t*)b->dec_byte_off.p;
+    w.out = nullptr;
+    // phase 1: sizes (the output is allocated once they are known)
+    HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, s));
+    jtk_launch_decode_count(w, s);
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, w.total, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = b->dec_out.ensure((size_t)total + 64))) return rc;
+    w.out = (uint8_t*)b->dec_out.p;
+    // phase 2: bytes and per-sequence offsets
+    jtk_launch_decode_scatter(w, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    b->dec_total = total;
+    b->have_decode = true;
+    if (n_bytes) *n_bytes = total;
+    return JTK_OK;
+}
+
+int jtk_batch_decode(jtk_batch* b, const int32_t* ids, const int64_t* seq_off, int64_t n_seqs, int64_t* n_bytes) {
+    if (!b || n_seqs < 0 || !seq_off) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (seq_off[0] != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "seq_off[0] must be 0");
+    for (int64_t q = 0; q < n_seqs; q++)
+        if (seq_off[q + 1] < seq_off[q]) return fail(JTK_ERR_INVALID_ARGUMENT, "seq_off must be non-decreasing");
+    const int64_t n_ids = seq_off[n_seqs];
+    if (n_ids > 0 && !ids) return fail(JTK_ERR_INVALID_ARGUMENT, "ids is NULL");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    int rc;
+    if ((rc = b->dec_in_ids.ensure((size_t)n_ids * 4 + 64)) || (rc = b->dec_in_off.ensure(((size_t)n_seqs + 1) * 8))) return rc;
+    if (n_ids > 0) HIP_TRY(hipMemcpyAsync(b->dec_in_ids.p, ids, (size_t)n_ids * 4, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->dec_in_off.p, seq_off, ((size_t)n_seqs + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    return jtk_batch_decode_device(b, (const int32_t*)b->dec_in_ids.p, (const int64_t*)b->dec_in_off.p, n_seqs, n_ids, nullptr, n_bytes);
+}
+
+int jtk_batch_decode_fetch(jtk_batch* b, uint8_t* out, int64_t out_cap, int64_t* byte_off, int32_t* status) {
+    if (!b || !b->have_decode) return fail(JTK_ERR_INVALID_ARGUMENT, "no decode has run on this batch");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    if (out) {
+        if (out_cap < b->dec_total) return fail(JTK_ERR_CAPACITY, "output buffer too small");
+        if (b->dec_total > 0) HIP_TRY(hipMemcpy(out, b->dwork.out, (size_t)b->dec_total, hipMemcpyDeviceToHost));
+    }
+    if (byte_off) HIP_TRY(hipMemcpy(byte_off, b->dwork.byte_off, ((size_t)b->dwork.n_seqs + 1) * 8, hipMemcpyDeviceToHost));
+    if (status && b->dwork.n_seqs > 0) HIP_TRY(hipMemcpy(status, b->dwork.status, (size_t)b->dwork.n_seqs * 4, hipMemcpyDeviceToHost));
+    return JTK_OK;
+}
+
+int jtk_batch_decode_device_result(jtk_batch* b, const uint8_t** d_out, const int64_t** d_byte_off, const int32_t** d_status) {
+    if (!b || !b->have_decode) return fail(JTK_ERR_INVALID_ARGUMENT, "no decode has run on this batch");
+    if (d_out) *d_out = b->dwork.out;
+    if (d_byte_off) *d_byte_off = b->dwork.byte_off;
+    if (d_status) *d_status = b->dwork.status;
     return JTK_OK;
 }
 

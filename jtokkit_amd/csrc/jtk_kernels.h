@@ -117,6 +117,28 @@ struct JtkWork {
     JtkResult* result;
 };
 
+// Device-side working set of one batch decode (jtk_decode.hip).
+#define JTK_DEC_TILE 2048        // tokens per decode workgroup
+struct JtkDecodeWork {
+    const int32_t* ids;         // all sequences' token ids back to back
+    const int64_t* seq_off;     // [n_seqs + 1]
+    int64_t n_tok, n_seqs, n_tiles;
+    const uint32_t* tab_off;    // [n_ids_table + 1] byte offset of every id's byte string in tab_blob (absent id: empty)
+    const uint8_t* tab_blob;
+    uint32_t n_ids_table;
+    uint64_t* seqmask;          // bit t: a sequence starts at token t (zeroed per call)
+    uint32_t* tile_bytes;       // [n_tiles]
+    int64_t* tile_off;          // [n_tiles + 1]
+    uint32_t* seqpre;           // at a sequence's first token: bytes of its tile before it (sparse)
+    int32_t* status;            // [n_seqs] (zeroed per call)
+    int32_t* worst_status;
+    int64_t* total;
+    uint8_t* out;               // NULL in the sizing phase
+    int64_t* byte_off;          // [n_seqs + 1]
+};
+void jtk_launch_decode_count(const JtkDecodeWork& w, hipStream_t s);     // mark, count, scan
+void jtk_launch_decode_scatter(const JtkDecodeWork& w, hipStream_t s);   // scatter, offsets
+
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);

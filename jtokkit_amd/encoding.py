@@ -121,6 +121,30 @@ class Batch:
         _check(N.lib().jtk_batch_device_result(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    # ---- batch decode (device) -------------------------------------------------------------------------
+    def decode_host(self, ids, seq_off):
+        """ids int32[n], seq_off int64[n_seqs+1] -> total byte count (result stays on the device)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        nb = C.c_int64(0)
+        _check(N.lib().jtk_batch_decode(self._h, ids.ctypes.data, seq_off.ctypes.data, len(seq_off) - 1, C.byref(nb)))
+        self._dec_shape = (nb.value, len(seq_off) - 1)
+        return nb.value
+
+    def decode_device(self, d_ids_ptr, d_seq_off_ptr, n_seqs, n_ids, stream=None):
+        nb = C.c_int64(0)
+        _check(N.lib().jtk_batch_decode_device(self._h, d_ids_ptr, d_seq_off_ptr, n_seqs, n_ids, stream, C.byref(nb)))
+        self._dec_shape = (nb.value, n_seqs)
+        return nb.value
+
+    def decode_fetch(self):
+        nb, ns = self._dec_shape
+        out = np.empty(max(nb, 1), dtype=np.uint8)
+        byte_off = np.empty(ns + 1, dtype=np.int64)
+        status = np.zeros(max(ns, 1), dtype=np.int32)
+        _check(N.lib().jtk_batch_decode_fetch(self._h, out.ctypes.data, nb, byte_off.ctypes.data, status.ctypes.data))
+        return out[:nb], byte_off, status[:ns]
+
     def set_profiling(self, on=True):
         _check(N.lib().jtk_batch_set_profiling(self._h, 1 if on else 0))
 
@@ -230,6 +254,22 @@ class HipEncoding:
         b = self._b()
         b.encode_host(text_u8, doc_off, ordinary, validate)
         return b.fetch()
+
+    def decode_batch(self, token_lists, strict=True):
+        """List of token-id lists -> list of bytes (Encoding.decodeBytes for each), one device call.
+        strict: raise for a list with an unknown id, as the reference does (GptBytePairEncoding.java:313)."""
+        seq_off = np.zeros(len(token_lists) + 1, dtype=np.int64)
+        if token_lists:
+            np.cumsum([len(t) for t in token_lists], out=seq_off[1:])
+        ids = np.fromiter((i for t in token_lists for i in t), dtype=np.int32, count=int(seq_off[-1]))
+        b = self._b()
+        b.decode_host(ids, seq_off)
+        out, byte_off, status = b.decode_fetch()
+        if strict and len(status) and status.min() < 0:
+            q = int(np.argmin(status))
+            raise EncodingError(int(status[q]), "Unknown token for decoding (list %d)" % q)
+        raw = out.tobytes()
+        return [raw[byte_off[q]:byte_off[q + 1]] for q in range(len(token_lists))]
 
     def vocab_size(self):
         return N.lib().jtk_encoding_vocab_size(self._h)

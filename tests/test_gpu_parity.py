@@ -252,3 +252,60 @@ def test_table_swap_back_to_back(jt):
         res = enc.encode_batch_packed(text, doc_off, ordinary=True)
         exp_tok, exp_off = oracle_lib.get(name).encode_batch(text, doc_off, threads=8)
         assert np.array_equal(res.tokens, exp_tok) and np.array_equal(res.tok_off, exp_off)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_batch_decode_golden_rows(jt, name):
+    """Device batch decode == the oracle's decodeBytes on the reference's expected token lists, and == the input
+    text (the round trip Cl100kBaseTestTest.java:33-37 checks), incl. empty lists."""
+    enc = jt.get_encoding(name)
+    o = oracle_lib.get(name)
+    rows = golden_util.load_rows(name)
+    lists = [r[1] for r in rows] + [[], rows[0][1], []]
+    got = enc.decode_batch(lists)
+    assert len(got) == len(lists)
+    for q, toks in enumerate(lists):
+        assert got[q] == o.decode_bytes(toks), q
+    for q, (inp, _, _) in enumerate(rows):
+        assert got[q] == inp.encode("utf-8")
+    assert enc.decode_batch([]) == []
+
+
+def test_batch_decode_unknown_and_special_ids(jt):
+    """Unknown id -> JTK_ERR_UNKNOWN_TOKEN for that list only (GptBytePairEncoding.java:313); special-token ids
+    decode to their literals (:308-311); p50k_base's hole at 50256 is the endoftext special."""
+    enc = jt.get_encoding("cl100k_base")
+    from jtokkit_amd import _native as N
+    b = enc.new_batch()
+    ids = np.array([15339, 1917, 15339, 999999, 1917, 100257, 15339, -5], dtype=np.int32)
+    seq_off = np.array([0, 2, 5, 6, 6, 8], dtype=np.int64)
+    nb = b.decode_host(ids, seq_off)
+    out, byte_off, status = b.decode_fetch()
+    assert status.tolist() == [0, N.JTK_ERR_UNKNOWN_TOKEN, 0, 0, N.JTK_ERR_UNKNOWN_TOKEN]
+    raw = out.tobytes()
+    assert raw[byte_off[0]:byte_off[1]] == b"hello world"
+    assert raw[byte_off[2]:byte_off[3]] == b"<|endoftext|>"
+    assert byte_off[3] == byte_off[4] and byte_off[-1] == nb == len(raw)
+    with pytest.raises(jt.EncodingError):
+        enc.decode_batch([[15339], [123456789]])
+    b.close()
+    p50k = jt.get_encoding("p50k_base")
+    assert p50k.decode_batch([[50256]]) == [b"<|endoftext|>"]
+    assert p50k.decode_batch([[50256]]) == [p50k.decode_bytes([50256])]
+
+
+def test_batch_decode_full_size_round_trip(jt):
+    """cfg-2-sized corpus: device decode of the device encode, document by document == the input bytes; mixed-script
+    corpus likewise (long tokens, tiles whose bytes exceed the LDS stage)."""
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding("cl100k_base")
+    for text, doc_off in (corpus.english(100000), corpus.mixed(2000)):
+        b = enc.new_batch()
+        b.encode_host(text, doc_off, ordinary=True)
+        res = b.fetch()
+        nb = b.decode_host(res.tokens, res.tok_off)
+        out, byte_off, status = b.decode_fetch()
+        assert nb == len(text) and (status == 0).all()
+        assert np.array_equal(byte_off, doc_off)
+        assert np.array_equal(out, text)
+        b.close()
