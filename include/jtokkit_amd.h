@@ -134,6 +134,16 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
  * byte strings of `ids`; *len receives the byte count (out may be NULL to size). */
 int jtk_decode(const jtk_encoding* enc, const int32_t* ids, int64_t n, uint8_t* out, int64_t cap, int64_t* len);
 
+/* ---- maxTokens for a whole batch, on the device ------------------------------------------------------
+ * Encoding.encode(String, int maxTokens) / encodeOrdinary(String, int) (GptBytePairEncoding.java:43-45, 66-69) for
+ * every document of the LAST batch encode on `b`: document d keeps the first kept[d] of its tokens
+ * ([tok_off[d], tok_off[d] + kept[d]) of the encode result) -- min(maxTokens, count) backed off to a code-point
+ * boundary exactly as :90-100 does -- and truncated[d] = EncodingResult.isTruncated() (:97).
+ * The input text of that encode must still be where it was (host-buffer encodes keep their own copy). */
+int jtk_batch_truncate(jtk_batch* b, int64_t max_tokens);
+int jtk_batch_fetch_truncated(jtk_batch* b, int64_t* kept, uint8_t* truncated);           /* [n_docs] each, may be NULL */
+int jtk_batch_device_truncated(jtk_batch* b, const int64_t** d_kept, const uint8_t** d_truncated);
+
 /* ---- batch decode on the device ---------------------------------------------------------------------
  * Replaces a loop of Encoding.decodeBytes(List<Integer>) (GptBytePairEncoding.java:137-151, 302-314; special-token
  * ids decode to their literals, :308-311) over n_seqs token lists: all ids back to back in `ids`, list q occupying

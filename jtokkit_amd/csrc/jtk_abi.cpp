@@ -69,6 +69,8 @@ struct jtk_batch {
         giant_list, giant_cnt, giant_off, giant_scratch, tokens, tok_off;
     // batch decode (jtk_batch_decode*)
     DevBuf dec_in_ids, dec_in_off, dec_zero, dec_tile, dec_pre, dec_out, dec_byte_off;
+    DevBuf trunc_kept, trunc_flag;   // jtk_batch_truncate
+    bool have_trunc = false;
     JtkDecodeWork dwork{};
     bool have_decode = false;
     int64_t dec_total = 0;
@@ -254,7 +256,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->plist, &b->htok, &b->docpre,
                       &b->tile_np, &b->tile_off, &b->queues, &b->qres, &b->q_meta, &b->giant_cnt, &b->mid_list, &b->long_list,
                       &b->giant_list, &b->giant_off, &b->giant_scratch, &b->dec_in_ids, &b->dec_in_off, &b->dec_zero,
-                      &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off,
+                      &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag,
                       &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
     if (b->ev_ok) { for (auto& ev : b->ev0) (void)hipEventDestroy(ev); for (auto& ev : b->ev1) (void)hipEventDestroy(ev); }
@@ -400,6 +402,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->host_result, w.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
     b->have_result = true;
+    b->have_trunc = false;
     b->synced = false;
     b->last_stream = s;
     b->giants_pending = true;
@@ -481,6 +484,42 @@ int jtk_batch_kernel_times(jtk_batch* b, const char** names, float* ms, int cap,
         if (ms) ms[i] = t;
         *n = i + 1;
     }
+    return JTK_OK;
+}
+
+// ---- maxTokens on the device ---------------------------------------------------------------------------
+int jtk_batch_truncate(jtk_batch* b, int64_t max_tokens) {
+    if (!b || !b->have_result || max_tokens < 0) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments (an encode must have run on this batch)");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
+    { const int rcg = finish_giants(b); if (rcg != JTK_OK) return rcg; }
+    const int64_t nd = b->work.n_docs;
+    int rc;
+    if ((rc = b->trunc_kept.ensure((size_t)(nd > 0 ? nd : 1) * 8)) || (rc = b->trunc_flag.ensure((size_t)(nd > 0 ? nd : 1)))) return rc;
+    JtkTruncWork t{};
+    t.tokens = b->work.tokens; t.tok_off = b->work.tok_off; t.text = b->work.text; t.doc_off = b->work.doc_off;
+    t.n_docs = nd; t.tab_off = (const uint32_t*)b->enc->dec_off.p; t.max_tokens = max_tokens;
+    t.kept = (int64_t*)b->trunc_kept.p; t.truncated = (uint8_t*)b->trunc_flag.p;
+    jtk_launch_truncate(t, b->last_stream);
+    HIP_TRY(hipGetLastError());
+    b->have_trunc = true;
+    return JTK_OK;
+}
+
+int jtk_batch_fetch_truncated(jtk_batch* b, int64_t* kept, uint8_t* truncated) {
+    if (!b || !b->have_trunc) return fail(JTK_ERR_INVALID_ARGUMENT, "jtk_batch_truncate has not run on this batch");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    const size_t nd = (size_t)b->work.n_docs;
+    if (kept && nd) HIP_TRY(hipMemcpy(kept, b->trunc_kept.p, nd * 8, hipMemcpyDeviceToHost));
+    if (truncated && nd) HIP_TRY(hipMemcpy(truncated, b->trunc_flag.p, nd, hipMemcpyDeviceToHost));
+    return JTK_OK;
+}
+
+int jtk_batch_device_truncated(jtk_batch* b, const int64_t** d_kept, const uint8_t** d_truncated) {
+    if (!b || !b->have_trunc) return fail(JTK_ERR_INVALID_ARGUMENT, "jtk_batch_truncate has not run on this batch");
+    if (d_kept) *d_kept = (const int64_t*)b->trunc_kept.p;
+    if (d_truncated) *d_truncated = (const uint8_t*)b->trunc_flag.p;
     return JTK_OK;
 }
 

@@ -150,7 +150,45 @@ __global__ void __launch_bounds__(256) k_dec_offsets(JtkDecodeWork w) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// truncate: Encoding.encode(text, maxTokens) for every document of the last batch encode
+// (GptBytePairEncoding.java:43-45, 79, 90-100, 110-119).  Pieces encode independently, so the list before
+// the back-off is the first min(maxTokens, total) tokens of the full result; the back-off (:90-100) drops
+// trailing tokens until decode(tokens) is a prefix of the text, i.e. until their bytes end on a code-point
+// boundary -- or in the middle of a U+FFFD of the text, which new String(bytes, UTF_8) turns into the
+// same U+FFFD.  truncated (:97) = text.length() > decoded.length().  One thread per document.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_truncate(JtkTruncWork w) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= w.n_docs) return;
+    const int64_t t0 = w.tok_off[d], cnt = w.tok_off[d + 1] - t0;
+    int64_t keep = cnt < w.max_tokens ? cnt : w.max_tokens;
+    uint8_t trunc = 0;
+    if (cnt > w.max_tokens) {
+        const uint8_t* tx = w.text + w.doc_off[d];
+        const int64_t len = w.doc_off[d + 1] - w.doc_off[d];
+        int64_t nb = 0;
+        for (int64_t k = 0; k < keep; k++) { const int32_t id = w.tokens[t0 + k]; nb += w.tab_off[id + 1] - w.tab_off[id]; }
+        for (;; keep--) {
+            const bool boundary = (nb == len) || ((tx[nb] & 0xC0) != 0x80);
+            if (boundary) { trunc = nb < len; break; }
+            int64_t c = nb;
+            while (c > 0 && (tx[c] & 0xC0) == 0x80) c--;
+            if (c + 2 < len && tx[c] == 0xEF && tx[c + 1] == 0xBF && tx[c + 2] == 0xBD) { trunc = c + 3 < len; break; }
+            if (keep == 0) break;
+            const int32_t id = w.tokens[t0 + keep - 1];
+            nb -= w.tab_off[id + 1] - w.tab_off[id];
+        }
+    }
+    w.kept[d] = keep;
+    w.truncated[d] = trunc;
+}
+
 }  // namespace
+
+void jtk_launch_truncate(const JtkTruncWork& w, hipStream_t s) {
+    if (w.n_docs > 0) hipLaunchKernelGGL(k_truncate, dim3((unsigned)((w.n_docs + 255) / 256)), dim3(256), 0, s, w);
+}
 
 void jtk_launch_decode_count(const JtkDecodeWork& w, hipStream_t s) {
     const int64_t n = w.n_seqs + 1;

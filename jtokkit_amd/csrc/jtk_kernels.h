@@ -136,6 +136,18 @@ struct JtkDecodeWork {
     uint8_t* out;               // NULL in the sizing phase
     int64_t* byte_off;          // [n_seqs + 1]
 };
+struct JtkTruncWork {
+    const int32_t* tokens;      // result of the last batch encode
+    const int64_t* tok_off;
+    const uint8_t* text;
+    const int64_t* doc_off;
+    int64_t n_docs;
+    const uint32_t* tab_off;    // decode table offsets (token byte lengths)
+    int64_t max_tokens;
+    int64_t* kept;              // [n_docs] tokens kept per document
+    uint8_t* truncated;         // [n_docs] EncodingResult.isTruncated()
+};
+void jtk_launch_truncate(const JtkTruncWork& w, hipStream_t s);
 void jtk_launch_decode_count(const JtkDecodeWork& w, hipStream_t s);     // mark, count, scan
 void jtk_launch_decode_scatter(const JtkDecodeWork& w, hipStream_t s);   // scatter, offsets
 

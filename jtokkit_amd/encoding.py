@@ -121,6 +121,16 @@ class Batch:
         _check(N.lib().jtk_batch_device_result(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    # ---- maxTokens for the whole batch (device) ---------------------------------------------------------
+    def truncate(self, max_tokens):
+        """Encoding.encode(text, maxTokens) for every document of the last encode -> (kept int64[n], truncated bool[n])."""
+        _check(N.lib().jtk_batch_truncate(self._h, int(max_tokens)))
+        _, nd, _ = self.result()
+        kept = np.zeros(max(nd, 1), dtype=np.int64)
+        flag = np.zeros(max(nd, 1), dtype=np.uint8)
+        _check(N.lib().jtk_batch_fetch_truncated(self._h, kept.ctypes.data, flag.ctypes.data))
+        return kept[:nd], flag[:nd].astype(bool)
+
     # ---- batch decode (device) -------------------------------------------------------------------------
     def decode_host(self, ids, seq_off):
         """ids int32[n], seq_off int64[n_seqs+1] -> total byte count (result stays on the device)."""
@@ -254,6 +264,22 @@ class HipEncoding:
         b = self._b()
         b.encode_host(text_u8, doc_off, ordinary, validate)
         return b.fetch()
+
+    def encode_batch_max_tokens(self, texts, max_tokens, ordinary=False):
+        """List of str/bytes -> list of EncodingResult, as Encoding.encode(text, maxTokens) gives for each."""
+        bs = [t if isinstance(t, (bytes, bytearray)) else t.encode("utf-8") for t in texts]
+        doc_off = np.zeros(len(bs) + 1, dtype=np.int64)
+        if bs:
+            np.cumsum([len(x) for x in bs], out=doc_off[1:])
+        text = np.frombuffer(b"".join(bs), dtype=np.uint8) if doc_off[-1] else np.zeros(0, dtype=np.uint8)
+        b = self._b()
+        b.encode_host(text, doc_off, ordinary)
+        res = b.fetch()
+        if len(res.status) and res.status.min() < 0:
+            _check(int(res.status.min()))
+        kept, flag = b.truncate(max_tokens)
+        return [EncodingResult(res.tokens[res.tok_off[d]:res.tok_off[d] + kept[d]].tolist(), bool(flag[d]))
+                for d in range(len(bs))]
 
     def decode_batch(self, token_lists, strict=True):
         """List of token-id lists -> list of bytes (Encoding.decodeBytes for each), one device call.

@@ -309,3 +309,37 @@ def test_batch_decode_full_size_round_trip(jt):
         assert np.array_equal(byte_off, doc_off)
         assert np.array_equal(out, text)
         b.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_batch_max_tokens_golden_rows(jt, name):
+    """encode(text, 10) for all fixture rows in one device call == the fixture's third column (tokens) and the
+    oracle's truncated flag (Cl100kBaseTestTest.java:40-67 semantics)."""
+    enc = jt.get_encoding(name)
+    o = oracle_lib.get(name)
+    rows = golden_util.load_rows(name)
+    got = enc.encode_batch_max_tokens([r[0] for r in rows], 10)
+    for (inp, _, expected10), r in zip(rows, got):
+        exp_toks, exp_tr = o.encode(inp, 10)
+        assert exp_toks == expected10
+        assert r.get_tokens() == expected10 and r.is_truncated() == exp_tr, inp
+
+
+def test_batch_max_tokens_fuzz(jt):
+    """Random mixed-script texts (multi-byte characters cut by the limit, U+FFFD in the text, empty documents),
+    several limits incl. 0: device truncation == oracle encode(text, max) == the per-call jtk_encode path."""
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    rng = random.Random(7)
+    texts = [rc.random_text(rng, rng.randint(0, 60)) for _ in range(300)]
+    texts += ["", "�", "a��b", "🍕🍕🍕", "I love 🍕", "�" * 7, "é" * 9, "한국어 텍스트 " * 5]
+    for mx in (0, 1, 2, 3, 5, 8, 13, 40, 10000):
+        got = enc.encode_batch_max_tokens(texts, mx, ordinary=True)
+        for t, r in zip(texts, got):
+            exp_toks, exp_tr = o.encode_ordinary(t, mx)
+            assert r.get_tokens() == exp_toks and r.is_truncated() == exp_tr, (mx, t)
+    for t in texts[::29] + texts[-8:]:
+        for mx in (1, 3, 7):
+            r = enc.encode_ordinary(t, mx)
+            exp_toks, exp_tr = o.encode_ordinary(t, mx)
+            assert r.get_tokens() == exp_toks and r.is_truncated() == exp_tr
