@@ -48,3 +48,18 @@ def get_encoding(name, device=0):
         if enc is None:
             enc = _cache[key] = new_encoding(name, device)
         return enc
+
+
+def new_custom_encoding(name, pattern_kind, mergeable_ranks, special_tokens=None, device=0):
+    """A custom byte-pair encoding on the device: what EncodingRegistry.registerGptBytePairEncoding(
+    GptBytePairEncodingParams(name, pattern, mergeableRanks, specialTokens)) builds in the reference
+    (api/GptBytePairEncodingParams.java:36-46, AbstractEncodingRegistry.java:64-66, EncodingFactory.java:117-119).
+
+    mergeable_ranks: {bytes: rank}.  pattern_kind: JTK_PATTERN_R50K or JTK_PATTERN_CL100K -- arbitrary
+    java.util.regex patterns are not supported.  The rank table must contain all 256 single bytes and reproduce
+    each of its entries under bytePairMerge (any table trained by byte-pair merging does); otherwise the C ABI
+    reports JTK_ERR_UNSUPPORTED_TABLE."""
+    import base64
+    lines = [base64.b64encode(k) + b" " + str(int(v)).encode() for k, v in sorted(mergeable_ranks.items(), key=lambda kv: kv[1])]
+    data = b"\n".join(lines) + b"\n"
+    return HipEncoding(name, pattern_kind, data, dict(special_tokens or {}), device)

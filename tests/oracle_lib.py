@@ -76,16 +76,19 @@ class OracleError(Exception):
 class OracleEncoding:
     """Mirrors the reference's Encoding interface (api/Encoding.java) on the CPU oracle."""
 
-    def __init__(self, name):
-        cfg = ENCODINGS[name]
+    def __init__(self, name, kind=None, data=None, specials=None):
+        """A predefined encoding by name, or (custom) any rank file bytes with one of the two patterns."""
         self.name = name
-        with open(os.path.join(DATA_DIR, cfg["file"]), "rb") as f:
-            data = f.read()
-        sp = b"".join(k.encode() + b"\0" for k in cfg["specials"])
-        ids = (C.c_int * len(cfg["specials"]))(*cfg["specials"].values())
-        self._h = lib().jtko_create(name.encode(), cfg["kind"], data, len(data), sp, ids, len(cfg["specials"]))
+        if data is None:
+            cfg = ENCODINGS[name]
+            kind, specials = cfg["kind"], cfg["specials"]
+            with open(os.path.join(DATA_DIR, cfg["file"]), "rb") as f:
+                data = f.read()
+        sp = b"".join(k.encode() + b"\0" for k in specials)
+        ids = (C.c_int * max(len(specials), 1))(*specials.values())
+        self._h = lib().jtko_create(name.encode(), kind, data, len(data), sp, ids, len(specials))
         if not self._h:
-            raise RuntimeError("oracle: could not load " + cfg["file"])
+            raise RuntimeError("oracle: could not load the rank table of " + name)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -343,3 +343,64 @@ def test_batch_max_tokens_fuzz(jt):
             r = enc.encode_ordinary(t, mx)
             exp_toks, exp_tr = o.encode_ordinary(t, mx)
             assert r.get_tokens() == exp_toks and r.is_truncated() == exp_tr
+
+
+def _train_tiny_bpe(corpus_bytes, n_merges, seed=0):
+    """A small byte-pair table trained the textbook way: all 256 bytes (ranks shuffled, as in the real tables where
+    rank != byte value), then n_merges merges of the most frequent adjacent pair inside whitespace-split words."""
+    rng = random.Random(seed)
+    order = list(range(256))
+    rng.shuffle(order)
+    ranks = {bytes([b]): r for r, b in enumerate(order)}
+    words = {}
+    for wd in corpus_bytes.split(b" "):
+        if wd:
+            key = tuple(bytes([c]) for c in b" " + wd)
+            words[key] = words.get(key, 0) + 1
+    for _ in range(n_merges):
+        pairs = {}
+        for wd, cnt in words.items():
+            for a, b2 in zip(wd, wd[1:]):
+                pairs[(a, b2)] = pairs.get((a, b2), 0) + cnt
+        if not pairs:
+            break
+        (a, b2), _ = max(pairs.items(), key=lambda kv: (kv[1], kv[0]))
+        if a + b2 in ranks:
+            break
+        ranks[a + b2] = len(ranks)
+        new_words = {}
+        for wd, cnt in words.items():
+            out, i = [], 0
+            while i < len(wd):
+                if i + 1 < len(wd) and wd[i] == a and wd[i + 1] == b2:
+                    out.append(a + b2); i += 2
+                else:
+                    out.append(wd[i]); i += 1
+            new_words[tuple(out)] = new_words.get(tuple(out), 0) + cnt
+        words = new_words
+    return ranks
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_custom_encoding(jt, kind):
+    """a custom rank table through the same kernels (registerGptBytePairEncoding /
+    GptBytePairEncodingParams in the reference), both shipped patterns; GPU == oracle built from the same table."""
+    import base64
+    from jtokkit_amd import corpus
+    text, doc_off = corpus.mixed(60, seed=11)
+    ranks = _train_tiny_bpe(corpus.english(40, seed=5)[0].tobytes() + " 日本語 の テキスト 한국어 ".encode() * 20, 600)
+    specials = {"<|endoftext|>": len(ranks) + 10}
+    enc = jt.new_custom_encoding("tiny_%d" % kind, kind, ranks, specials)
+    data = b"\n".join(base64.b64encode(k) + b" " + str(v).encode() for k, v in sorted(ranks.items(), key=lambda kv: kv[1])) + b"\n"
+    o = oracle_lib.OracleEncoding("tiny_%d" % kind, kind, data, specials)
+    assert enc.vocab_size() == len(ranks)
+    res = enc.encode_batch_packed(text, doc_off, ordinary=True)
+    exp_tok, exp_off = o.encode_batch(text, doc_off, threads=4)
+    assert np.array_equal(res.tokens, exp_tok) and np.array_equal(res.tok_off, exp_off)
+    rng = random.Random(3)
+    texts = [rc.random_text(rng, rng.randint(0, 80)) for _ in range(200)]
+    _assert_batch_equals_oracle(enc, o, texts)
+    assert enc.decode_batch([res.doc(d).tolist() for d in range(5)]) == [text[doc_off[d]:doc_off[d + 1]].tobytes() for d in range(5)]
+    with pytest.raises(jt.UnsupportedOperationError):
+        enc.encode("a <|endoftext|> b")
+    enc.close()
