@@ -601,7 +601,13 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     uint32_t* const rk = s_rk + tid;
 
     enum { ST_NEED = 0, ST_TEXT = 1, ST_EXPAND = 2, ST_MERGE = 3, ST_EMIT = 4, ST_DONE = 5 };
-    constexpr int BATCH = 24;
+#ifndef JTK_EXPAND_BATCH
+#define JTK_EXPAND_BATCH 48
+#endif
+#ifndef JTK_EMIT_BATCH
+#define JTK_EMIT_BATCH 48
+#endif
+    constexpr int BATCH = JTK_EXPAND_BATCH, EMIT_BATCH = JTK_EMIT_BATCH;   // lanes that have to wait before the divergent steps run
     int st = ST_NEED;
     uint32_t qi = 0, slot = 0;
     int64_t pos = 0;
@@ -761,7 +767,7 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
         // the tile's slots, leave their tokens in htok, packed from the piece's first byte position.  The count also
         // replaces the queue entry, where k_tile_counts sums it.
         const uint64_t b_emit = __ballot(st == ST_EMIT);
-        if (b_emit && (__popcll(b_emit) >= BATCH || !b_merge)) {
+        if (b_emit && (__popcll(b_emit) >= EMIT_BATCH || !b_merge)) {
             if (st == ST_EMIT) {
                 uint32_t c = 0;
 #pragma unroll
