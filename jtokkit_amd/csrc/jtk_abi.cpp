@@ -53,7 +53,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct jtk_encoding {
     JtkHostTables host;
     int device = 0;
-    DevBuf uc1, uc2, brank, pairs, tok8, bprank, bpbits, bpcum, bpranks, pairin, dec_off, dec_blob;
+    DevBuf uc1, uc2, brank, pairs, tok8, tok16, bprank, bpbits, bpcum, bpranks, pairin, dec_off, dec_blob;
     uint32_t n_ids_table = 0;        // ids 0 .. n_ids_table-1 have an entry in the decode table (incl. special tokens)
     JtkDeviceTables dt;
     std::vector<uint32_t> tok_len;   // byte length per id (0 = absent), for the maxTokens back-off
@@ -154,18 +154,20 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     }
     if (device < 0 || device >= ndev) { delete enc; return fail(JTK_ERR_INVALID_ARGUMENT, "device index out of range"); }
     enc->device = device;
-    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); delete enc; };
+    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); delete enc; };
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(JTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     ENC_TRY(hipSetDevice(device));
     if (enc->uc1.ensure(sizeof(jtk_uc_stage1_init)) || enc->uc2.ensure(sizeof(jtk_uc_stage2_init)) ||
         enc->brank.ensure(256 * 4) || enc->pairs.ensure(enc->host.pair_buckets.size() * sizeof(JtkPairBucket)) ||
-        enc->tok8.ensure(enc->host.tok8.size() * sizeof(JtkTok8Slot)) || enc->bprank.ensure(65536 * 4) ||
+        enc->tok8.ensure(enc->host.tok8.size() * sizeof(JtkTok8Slot)) || enc->tok16.ensure(enc->host.tok16.size() * sizeof(JtkTok16Slot)) ||
+        enc->bprank.ensure(65536 * 4) ||
         enc->bpbits.ensure(1024 * 8) || enc->bpcum.ensure(1024 * 2) || enc->bpranks.ensure(JTK_BP_MAX * 4) || enc->pairin.ensure(2048 * 4)) { cleanup(); return JTK_ERR_OUT_OF_MEMORY; }
     ENC_TRY(hipMemcpy(enc->uc1.p, jtk_uc_stage1_init, sizeof(jtk_uc_stage1_init), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->uc2.p, jtk_uc_stage2_init, sizeof(jtk_uc_stage2_init), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->brank.p, enc->host.byte_rank, 256 * 4, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->pairs.p, enc->host.pair_buckets.data(), enc->host.pair_buckets.size() * sizeof(JtkPairBucket), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->tok8.p, enc->host.tok8.data(), enc->host.tok8.size() * sizeof(JtkTok8Slot), hipMemcpyHostToDevice));
+    ENC_TRY(hipMemcpy(enc->tok16.p, enc->host.tok16.data(), enc->host.tok16.size() * sizeof(JtkTok16Slot), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bprank.p, enc->host.bp_rank.data(), 65536 * 4, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bpbits.p, enc->host.bp_bits.data(), 1024 * 8, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bpcum.p, enc->host.bp_cum.data(), 1024 * 2, hipMemcpyHostToDevice));
@@ -197,6 +199,8 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     dt.pairs.bits = enc->host.pair_bits;
     dt.tok8.slots = (const JtkTok8Slot*)enc->tok8.p;
     dt.tok8.bits = enc->host.tok8_bits;
+    dt.tok16.slots = (const JtkTok16Slot*)enc->tok16.p;
+    dt.tok16.n = enc->host.tok16_n;
     dt.bp_rank = (const uint32_t*)enc->bprank.p;
     dt.bp.bits = (const uint64_t*)enc->bpbits.p;
     dt.bp.cum = (const uint16_t*)enc->bpcum.p;
@@ -217,7 +221,7 @@ void jtk_encoding_destroy(jtk_encoding* enc) {
     if (!enc) return;
     (void)hipSetDevice(enc->device);
     enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release();
-    enc->tok8.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release();
+    enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release();
     delete enc;
 }
 const char* jtk_encoding_name(const jtk_encoding* enc) { return enc ? enc->host.name.c_str() : ""; }

@@ -153,6 +153,33 @@ JTK_HD uint32_t jtk_tok8_hash2(uint32_t lo, uint32_t hi, uint32_t len, uint32_t 
     return jtk_reduce32(h, nslots);
 }
 
+// ---- whole-piece table for pieces of 9..16 bytes ------------------------------------------------------
+// Same shortcut (GptBytePairEncoding.java:81-83) for the longer words of ordinary text, which would otherwise
+// cost the most merge steps.  Key = 16 bytes little-endian in k[4], zero padded, plus the length.  32-byte slots,
+// two-choice cuckoo, one slot per choice.
+struct JtkTok16Slot {
+    uint32_t k[4];
+    uint32_t id, len, pad0, pad1;   // len == 0: empty
+};
+struct JtkTok16Table {
+    const JtkTok16Slot* slots;
+    uint32_t n;
+};
+JTK_HD uint32_t jtk_tok16_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len, uint32_t nslots) {
+    uint32_t h = k0 * 0x9E3779B1u + k1 * 0x85EBCA77u + k2 * 0xC2B2AE3Du + (k3 ^ (len << 27)) * 0x27D4EB2Fu;
+    h ^= h >> 16;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return jtk_reduce32(h, nslots);
+}
+JTK_HD uint32_t jtk_tok16_hash2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len, uint32_t nslots) {
+    uint32_t h = (k0 ^ (len << 29)) * 0xC2B2AE3Du + k1 * 0x27D4EB2Fu + k2 * 0x9E3779B1u + k3 * 0x165667B1u + 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return jtk_reduce32(h, nslots);
+}
+
 // ---- Unicode class lookup ----------------------------------------------------------------------------
 struct JtkUcTables {
     const uint8_t* stage1;    // [0x1100]  cp >> 8 -> block

@@ -44,6 +44,7 @@ struct JtkDeviceTables {
     const uint32_t* byte_rank;   // [256]
     JtkPairTable pairs;
     JtkTok8Table tok8;
+    JtkTok16Table tok16;
     const uint32_t* bp_rank;     // [65536]
     JtkBpLds bp;                 // the same, compressed (staged into LDS by bpe_merge)
     const uint32_t* pair_in_token;   // [2048] bit (b0 << 8 | b1): adjacent inside some table entry

@@ -225,7 +225,44 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
     }
 
-    // The shortcut is applied only to pieces of <= 8 bytes on the device; everything else goes through
+    {   // whole pieces of 9..16 bytes
+        std::vector<JtkTok16Slot> mids;
+        for (auto& kv : t.bytes_to_id) {
+            const std::string& T = kv.first;
+            if (T.size() < 9 || T.size() > 16) continue;
+            JtkTok16Slot e{{0, 0, 0, 0}, kv.second, (uint32_t)T.size(), 0, 0};
+            for (size_t k = 0; k < T.size(); k++) e.k[k >> 2] |= (uint32_t)(uint8_t)T[k] << (8 * (k & 3));
+            mids.push_back(e);
+        }
+        t.n_tok16 = (int64_t)mids.size();
+        double load = 0.45;
+        for (;; load *= 0.9) {
+            const uint32_t ns = (uint32_t)((double)mids.size() / load) + 16;
+            std::vector<JtkTok16Slot> slots(ns, JtkTok16Slot{{0, 0, 0, 0}, 0, 0, 0, 0});
+            uint32_t rng = 0x1357u;
+            bool ok = true;
+            for (auto cur : mids) {
+                bool placed = false;
+                for (int kick = 0; kick < 5000 && !placed; kick++) {
+                    const uint32_t h[2] = {jtk_tok16_hash(cur.k[0], cur.k[1], cur.k[2], cur.k[3], cur.len, ns),
+                                           jtk_tok16_hash2(cur.k[0], cur.k[1], cur.k[2], cur.k[3], cur.len, ns)};
+                    for (int c = 0; c < 2 && !placed; c++)
+                        if (slots[h[c]].len == 0) { slots[h[c]] = cur; placed = true; }
+                    if (!placed) {
+                        rng = rng * 1664525u + 1013904223u;
+                        std::swap(cur, slots[h[(rng >> 16) & 1]]);
+                    }
+                }
+                if (!placed) { ok = false; break; }
+            }
+            if (!ok) continue;
+            t.tok16_n = ns;
+            t.tok16 = slots;
+            break;
+        }
+    }
+
+    // The shortcut is applied only to pieces of <= 16 bytes on the device; everything else goes through
     // bytePairMerge.  That is only equivalent to GptBytePairEncoding.java:81-86 when merging any table
     // token on its own yields exactly that token.
     JtkPairTable pt{t.pair_buckets.data(), t.pair_bits};

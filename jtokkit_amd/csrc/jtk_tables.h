@@ -21,6 +21,9 @@ struct JtkHostTables {
     std::vector<JtkTok8Slot> tok8;               // whole-piece table, pieces of <= 8 bytes
     uint32_t tok8_bits = 0;
     int64_t n_tok8 = 0;
+    std::vector<JtkTok16Slot> tok16;             // whole-piece table, pieces of 9..16 bytes
+    uint32_t tok16_n = 0;
+    int64_t n_tok16 = 0;
     std::vector<uint32_t> bp_rank;               // [65536] rank of the 2-byte token (b0 << 8 | b1), or NONE
     // the same table compressed for LDS: membership bitmap, per-word running count, ranks in index order
     std::vector<uint32_t> pair_in_token;         // [2048] bit (b0 << 8 | b1): the two bytes are adjacent inside some table entry
