@@ -64,7 +64,7 @@ def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16):
 
 
 # stage (HIP-event bracket in jtk_batch_kernel_times) -> the kernel it launches, as rocprofv3 names it
-STAGE_KERNEL = {"bpe_merge16": "k_bpe_merge<16, 1024, 0>", "piece_resolve": "k_piece_resolve",
+STAGE_KERNEL = {"bpe_merge": "k_bpe_merge_all", "piece_resolve": "k_piece_resolve",
                 "pretok_split": "k_pretok_split<1>", "mark_docs": "k_mark_docs", "special_check": "k_special_check"}
 
 

@@ -42,9 +42,8 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-constexpr int N_STAGES = 8;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge16",
-                                           "bpe_merge_bins", "bpe_merge_long", "pack"};
+constexpr int N_STAGES = 6;
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge", "pack"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -79,8 +78,6 @@ struct jtk_batch {
     JtkWork work{};
     bool have_result = false, synced = false;
     bool profiling = false;
-    hipStream_t side = nullptr;          // the kernels for pieces of more than 16 bytes are launched here
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0[N_STAGES] = {}, ev1[N_STAGES] = {};   // start / end of each stage, on the stream it runs on
     bool ev_ok = false, ev_recorded = false;
 };
@@ -237,14 +234,8 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
     if (!b) return fail(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
     b->enc = enc;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result, sizeof(JtkResult), hipHostMallocDefault);
     if (e != hipSuccess) {
-        if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-        if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-        if (b->side) (void)hipStreamDestroy(b->side);
         if (b->stream) (void)hipStreamDestroy(b->stream);
         delete b;
         return fail(JTK_ERR_HIP, std::string("batch create: ") + hipGetErrorString(e));
@@ -265,10 +256,6 @@ void jtk_batch_destroy(jtk_batch* b) {
     for (DevBuf* d : bufs) d->release();
     if (b->ev_ok) { for (auto& ev : b->ev0) (void)hipEventDestroy(ev); for (auto& ev : b->ev1) (void)hipEventDestroy(ev); }
     if (b->host_result) (void)hipHostFree(b->host_result);
-    (void)hipEventDestroy(b->ev_fork);
-    (void)hipEventDestroy(b->ev_join);
-    (void)hipStreamSynchronize(b->side);
-    (void)hipStreamDestroy(b->side);
     (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -383,23 +370,9 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     begin(s);
     jtk_launch_piece_resolve(w, enc->dt, s);
     end(s);
-    // fork: the kernels for pieces of more than 16 bytes are launched on a side stream.  Every merge workgroup
-    // needs a whole CU's LDS, so their work does not overlap with k_bpe_merge<16>, but on ordinary text they are
-    // six nearly empty launches whose launch latencies now hide under it (3 % of the step at cfg 2).
-    hipStream_t sd = b->side;
-    HIP_TRY(hipEventRecord(b->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(sd, b->ev_fork, 0));
     begin(s);
-    jtk_launch_bpe_merge16(w, enc->dt, s);
+    jtk_launch_bpe_merge(w, enc->dt, s);
     end(s);
-    begin(sd);
-    jtk_launch_bpe_merge_bins(w, enc->dt, sd);
-    end(sd);
-    begin(sd);
-    jtk_launch_bpe_merge_long(w, enc->dt, sd);
-    end(sd);
-    HIP_TRY(hipEventRecord(b->ev_join, sd));
-    HIP_TRY(hipStreamWaitEvent(s, b->ev_join, 0));
     begin(s);
     jtk_launch_pack(w, s);
     end(s);

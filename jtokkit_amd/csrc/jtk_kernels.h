@@ -157,9 +157,7 @@ void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStr
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
-void jtk_launch_bpe_merge16(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);    // pieces of <= 16 bytes
-void jtk_launch_bpe_merge_bins(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);  // 17..256 bytes
-void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // pieces of up to 8192 bytes
 void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
                                 uint32_t* scratch, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);

@@ -610,16 +610,26 @@ template <int NW> __device__ __forceinline__ void mask_init(uint64_t (&w)[NW], i
     }
 }
 
+// LDS of the merge kernel, shared by all its phases
+struct MergeLds {
+    uint32_t* id;            // [16384] parts: token ids, [slot][lane]
+    uint32_t* rk;            // [16384] parts: pair keys
+    const uint64_t* bpbits;
+    const uint32_t* bpranks;
+    const uint16_t* bpcum;
+    const uint32_t* brank;
+    uint32_t* next;          // [JTK_NBINS] queue positions handed out, one counter per bin
+};
+
+// One length bin: the first THREADS lanes of the workgroup drain this workgroup's chunks of the bin's queue shard.
 template <int SLOTS, int THREADS, int BIN>
-__global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint32_t s_id[SLOTS * THREADS];
-    __shared__ uint32_t s_rk[SLOTS * THREADS];
-    __shared__ uint64_t s_bpbits[1024];
-    __shared__ uint32_t s_bpranks[JTK_BP_MAX];
-    __shared__ uint16_t s_bpcum[1024];
-    __shared__ uint32_t s_brank[256];
-    __shared__ uint32_t s_next;
+__device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTables& t, const MergeLds& L) {
     const int tid = threadIdx.x, lane = tid & 63;
+    if (tid >= THREADS) return;
+    uint32_t* const s_id = L.id;
+    uint32_t* const s_rk = L.rk;
+    const uint32_t* const s_brank = L.brank;
+    uint32_t& s_next = L.next[BIN];
 
     // dense queue shard `shard`; this workgroup takes chunks kq, kq + K, kq + 2K, ... of it
     const int shard = blockIdx.x % JTK_Q_SHARDS;
@@ -628,12 +638,7 @@ __global__ void __launch_bounds__(THREADS) k_bpe_merge(JtkWork w, JtkDeviceTable
     if ((uint64_t)kq * M_CHUNK >= count) return;
     uint64_t* const queue = w.q[BIN] + (int64_t)shard * w.q_cap[BIN];     // entries are read in aligned pairs
 
-    for (int i = tid; i < 1024; i += THREADS) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
-    for (int i = tid; i < JTK_BP_MAX; i += THREADS) s_bpranks[i] = t.bp.ranks[i];
-    for (int i = tid; i < 256; i += THREADS) s_brank[i] = t.byte_rank[i];
-    if (tid == 0) s_next = 0;
-    __syncthreads();
-    const JtkBpLds bp{s_bpbits, s_bpcum, s_bpranks};
+    const JtkBpLds bp{L.bpbits, L.bpcum, L.bpranks};
     const JtkPairTable pt = t.pairs;
     uint32_t* const id = s_id + tid;
     uint32_t* const rk = s_rk + tid;
@@ -892,14 +897,14 @@ __device__ void merge_piece_wave(uint32_t* ids, uint32_t* rk, int len, const Jtk
     }
 }
 
+// wave `wave_id` of `n_waves` takes every n_waves-th piece of the list; parts in this wave's LDS region (CAP words each)
 template <int CAP>
-__global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint32_t s_id[CAP];
-    __shared__ uint32_t s_rk[CAP];
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTables& t, uint32_t* s_id, uint32_t* s_rk,
+                                           uint32_t wave_id, uint32_t n_waves) {
+    const int lane = threadIdx.x & 63;
     const JtkLongPiece* list = (CAP == JTK_MID_CAP) ? w.mid_list : w.long_list;
     const uint32_t cnt = (CAP == JTK_MID_CAP) ? *w.mid_count : *w.long_count;
-    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+    for (uint32_t i = wave_id; i < cnt; i += n_waves) {
         const JtkLongPiece lp = list[i];
         if (lp.len > CAP) {
             if (lane == 0) {
@@ -939,6 +944,45 @@ __global__ void __launch_bounds__(64) k_bpe_merge_long(JtkWork w, JtkDeviceTable
         }
         wave_lds_fence();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_bpe_merge_all: ONE persistent launch for all of bytePairMerge (except the giant pieces): the five length bins
+// one after the other, then the wave-per-piece lists.  All phases share the 128 KiB of LDS parts and the staged
+// tables; a workgroup barrier separates them (their LDS layouts differ), but there is no device-wide barrier and
+// no launch gap between them, and on ordinary text the later phases find empty queues and cost nothing.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTables t) {
+    __shared__ uint32_t s_id[16384];
+    __shared__ uint32_t s_rk[16384];
+    __shared__ uint64_t s_bpbits[1024];
+    __shared__ uint32_t s_bpranks[JTK_BP_MAX];
+    __shared__ uint16_t s_bpcum[1024];
+    __shared__ uint32_t s_brank[256];
+    __shared__ uint32_t s_next[JTK_NBINS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 1024; i += 1024) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
+    for (int i = tid; i < JTK_BP_MAX; i += 1024) s_bpranks[i] = t.bp.ranks[i];
+    for (int i = tid; i < 256; i += 1024) s_brank[i] = t.byte_rank[i];
+    if (tid < JTK_NBINS) s_next[tid] = 0;
+    __syncthreads();
+    const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next};
+    merge_bin<16, 1024, 0>(w, t, L);
+    __syncthreads();
+    merge_bin<32, 512, 1>(w, t, L);
+    __syncthreads();
+    merge_bin<64, 256, 2>(w, t, L);
+    __syncthreads();
+    merge_bin<128, 128, 3>(w, t, L);
+    __syncthreads();
+    merge_bin<256, 64, 4>(w, t, L);
+    __syncthreads();
+    // pieces of 257..512 bytes: every wave of the grid takes pieces, parts in its own 2 x 512 words
+    const uint32_t wv = (uint32_t)tid >> 6;
+    merge_long<JTK_MID_CAP>(w, t, s_id + wv * JTK_MID_CAP, s_rk + wv * JTK_MID_CAP, blockIdx.x * 16u + wv, gridDim.x * 16u);
+    __syncthreads();
+    // pieces of 513..8192 bytes: one wave per workgroup, parts in 2 x 8192 words
+    if (wv == 0) merge_long<JTK_LONG_CAP>(w, t, s_id, s_rk, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1315,20 +1359,8 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
 }
-void jtk_launch_bpe_merge16(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    const dim3 grid(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD);
-    hipLaunchKernelGGL((k_bpe_merge<16, 1024, 0>), grid, dim3(1024), 0, s, w, t);
-}
-void jtk_launch_bpe_merge_bins(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    const dim3 grid(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD);
-    hipLaunchKernelGGL((k_bpe_merge<32, 512, 1>), grid, dim3(512), 0, s, w, t);
-    hipLaunchKernelGGL((k_bpe_merge<64, 256, 2>), grid, dim3(256), 0, s, w, t);
-    hipLaunchKernelGGL((k_bpe_merge<128, 128, 3>), grid, dim3(128), 0, s, w, t);
-    hipLaunchKernelGGL((k_bpe_merge<256, 64, 4>), grid, dim3(64), 0, s, w, t);
-}
-void jtk_launch_bpe_merge_long(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    hipLaunchKernelGGL(k_bpe_merge_long<JTK_MID_CAP>, dim3(2048), dim3(64), 0, s, w, t);
-    hipLaunchKernelGGL(k_bpe_merge_long<JTK_LONG_CAP>, dim3(256), dim3(64), 0, s, w, t);
+void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
+    hipLaunchKernelGGL(k_bpe_merge_all, dim3(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD), dim3(1024), 0, s, w, t);
 }
 void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
                                 uint32_t* scratch, hipStream_t s) {
