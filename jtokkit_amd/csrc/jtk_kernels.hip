@@ -376,8 +376,7 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __shared__ uint32_t s_cnt[TW];
     __shared__ uint32_t s_pre[TW + 1];
     __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
-    __shared__ uint32_t s_t16[T / 8];          // pieces of 9..16 bytes, looked up whole after the main rounds: offset | list index << 11 | len << 22
-    __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_nhard, s_nt16;
+    __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -401,7 +400,7 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         s_cnt[tid] = (uint32_t)__popcll(m);
     }
     if (tid < JTK_NBINS) s_qn[tid] = 0;
-    if (tid == 0) { s_nhard = 0; s_nt16 = 0; }
+    if (tid == 0) s_nhard = 0;
     if (tid == 64) {
         int64_t pos = -1;                                             // scan ahead for the next piece start
         for (int64_t wd = (B >> 6) + TW; pos < 0 && wd < w.n_words; wd++) {
@@ -420,11 +419,14 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     }
     __syncthreads();
 
-    // one lane per piece, four rounds of table probes in flight per lane
+    // One lane per piece, two pieces per lane in flight.  A piece of <= 8 bytes looks itself up in the tok8 table, one
+    // of 9..16 bytes in the tok16 table (the reference's whole-piece shortcut, :81-83); either way the lane issues the
+    // same four loads (two slots; key and id/length words), so there is no divergence around the loads.
     const int64_t next_after = s_next_after;
     const JtkTok8Slot* t8 = t.tok8.slots;
+    const JtkTok16Slot* t16 = t.tok16.slots;
     uint32_t* const plist = w.plist + B;
-    struct Probe { int s, len; uint32_t lo, hi, ax, ay, az, aw, bx, by, bz, bw; };
+    struct Probe { int s, len; uint32_t k0, k1, k2, k3; uint4 ka, kb; uint2 ma, mb; };
     auto piece_len = [&](int k, int s) -> int64_t {
         int64_t e;
         if (k + 1 < np) e = s_plist[k + 1];
@@ -440,12 +442,32 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
             pr.s = s;
             pr.len = len64 > 0x10000 ? 0x10000 : (int)len64;
         }
-        if (pr.s >= 0 && pr.len <= 8) {
-            piece_key(s_tx, pr.s, pr.len, pr.lo, pr.hi);
-            const uint4 va = *reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash(pr.lo, pr.hi, (uint32_t)pr.len, t.tok8.bits)]);
-            const uint4 vb = *reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash2(pr.lo, pr.hi, (uint32_t)pr.len, t.tok8.bits)]);
-            pr.ax = va.x; pr.ay = va.y; pr.az = va.z; pr.aw = va.w;
-            pr.bx = vb.x; pr.by = vb.y; pr.bz = vb.z; pr.bw = vb.w;
+        if (pr.s >= 0 && pr.len <= 16) {
+            // up to 16 bytes of the piece, zero beyond its length
+            const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
+            const int a = pr.s >> 2;
+            const uint32_t sh = (uint32_t)(pr.s & 3);
+            const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2], w3 = tw[a + 3], w4 = tw[a + 4];
+            uint32_t k[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                             __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)};
+            const uint32_t len = (uint32_t)pr.len, part = (1u << (8u * (len & 3u))) - 1u;   // mask of the last, partial word
+#pragma unroll
+            for (int q = 0; q < 4; q++) k[q] &= (len >= 4u * q + 4u) ? ~0u : (len > 4u * q ? part : 0u);
+            pr.k0 = k[0]; pr.k1 = k[1]; pr.k2 = k[2]; pr.k3 = k[3];
+            const uint4 *pa, *pb;
+            const uint2 *qa, *qb;
+            if (len <= 8) {
+                pa = reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash(k[0], k[1], len, t.tok8.bits)]);
+                pb = reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash2(k[0], k[1], len, t.tok8.bits)]);
+                qa = reinterpret_cast<const uint2*>(pa) + 1;           // (id, len) of the 16-byte slot
+                qb = reinterpret_cast<const uint2*>(pb) + 1;
+            } else {
+                pa = reinterpret_cast<const uint4*>(&t16[jtk_tok16_hash(k[0], k[1], k[2], k[3], len, t.tok16.n)]);
+                pb = reinterpret_cast<const uint4*>(&t16[jtk_tok16_hash2(k[0], k[1], k[2], k[3], len, t.tok16.n)]);
+                qa = reinterpret_cast<const uint2*>(pa + 1);           // (id, len) after the 16-byte key
+                qb = reinterpret_cast<const uint2*>(pb + 1);
+            }
+            pr.ka = *pa; pr.kb = *pb; pr.ma = *qa; pr.mb = *qb;
         }
     };
     auto resolve = [&](int k, const Probe& pr) {
@@ -453,14 +475,16 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         const int s = pr.s, len = pr.len;
         uint32_t entry = JTK_PL_HARD | JTK_PL_NOQUEUE | (uint32_t)s;
         int bin = -1;
-        if (len <= 8) {
+        if (len <= 16) {
             uint32_t id = JTK_RANK_NONE;
-            if (pr.aw == (uint32_t)len && pr.ax == pr.lo && pr.ay == pr.hi) id = pr.az;
-            else if (pr.bw == (uint32_t)len && pr.bx == pr.lo && pr.by == pr.hi) id = pr.bz;
+            if (len <= 8) {
+                if (pr.ma.y == (uint32_t)len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1) id = pr.ma.x;
+                else if (pr.mb.y == (uint32_t)len && pr.kb.x == pr.k0 && pr.kb.y == pr.k1) id = pr.mb.x;
+            } else {
+                if (pr.ma.y == (uint32_t)len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1 && pr.ka.z == pr.k2 && pr.ka.w == pr.k3) id = pr.ma.x;
+                else if (pr.mb.y == (uint32_t)len && pr.kb.x == pr.k0 && pr.kb.y == pr.k1 && pr.kb.z == pr.k2 && pr.kb.w == pr.k3) id = pr.mb.x;
+            }
             if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT); else bin = 0;
-        } else if (len <= 16) {
-            s_t16[atomicAdd(&s_nt16, 1u)] = (uint32_t)s | ((uint32_t)k << 11) | ((uint32_t)len << 22);
-            return;                                                   // list entry written after the whole-piece lookup
         } else if (len <= 32) bin = 1;
         else if (len <= 64) bin = 2;
         else if (len <= 128) bin = 3;
@@ -479,51 +503,12 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         }
         plist[k] = entry;
     };
-    for (int k0 = 0; k0 < np; k0 += 4 * 256) {
-        Probe p0, p1, p2, p3;
+    for (int k0 = 0; k0 < np; k0 += 2 * 256) {
+        Probe p0, p1;
         issue(k0 + tid, p0);
         issue(k0 + 256 + tid, p1);
-        issue(k0 + 512 + tid, p2);
-        issue(k0 + 768 + tid, p3);
         resolve(k0 + tid, p0);
         resolve(k0 + 256 + tid, p1);
-        resolve(k0 + 512 + tid, p2);
-        resolve(k0 + 768 + tid, p3);
-    }
-    __syncthreads();
-    // pieces of 9..16 bytes (the longer words of ordinary text): one lane each, whole-piece lookup in the tok16 table
-    // (two 32-byte slots, all loads in flight); a hit resolves the piece, a miss queues it in bin 0
-    {
-        const uint32_t nt16 = s_nt16;
-        const JtkTok16Slot* t16 = t.tok16.slots;
-        for (uint32_t i = tid; i < nt16; i += 256) {
-            const uint32_t e = s_t16[i];
-            const int s = (int)(e & 2047u), k = (int)((e >> 11) & 2047u), len = (int)(e >> 22);
-            const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
-            const int a = s >> 2;
-            const uint32_t sh = (uint32_t)(s & 3);
-            const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2], w3 = tw[a + 3], w4 = tw[a + 4];
-            uint32_t k0 = __builtin_amdgcn_alignbyte(w1, w0, sh), k1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            uint32_t k2 = __builtin_amdgcn_alignbyte(w3, w2, sh), k3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
-            // zero the bytes beyond len (9..16: k0, k1 are whole)
-            if (len < 12) { k2 &= (1u << (8 * (len - 8))) - 1u; k3 = 0; }
-            else if (len == 12) k3 = 0;
-            else if (len < 16) k3 &= (1u << (8 * (len - 12))) - 1u;
-            const uint4* pa = reinterpret_cast<const uint4*>(&t16[jtk_tok16_hash(k0, k1, k2, k3, (uint32_t)len, t.tok16.n)]);
-            const uint4* pb = reinterpret_cast<const uint4*>(&t16[jtk_tok16_hash2(k0, k1, k2, k3, (uint32_t)len, t.tok16.n)]);
-            const uint4 ak = pa[0], am = pa[1], bk = pb[0], bm = pb[1];
-            uint32_t id = JTK_RANK_NONE;
-            if (am.y == (uint32_t)len && ak.x == k0 && ak.y == k1 && ak.z == k2 && ak.w == k3) id = am.x;
-            else if (bm.y == (uint32_t)len && bk.x == k0 && bk.y == k1 && bk.z == k2 && bk.w == k3) id = bm.x;
-            uint32_t entry;
-            if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT);
-            else {
-                const uint32_t qi = atomicAdd(&s_qn[0], 1u);
-                s_q[Q_OFF0 + qi] = (uint32_t)s | ((uint32_t)(len - 1) << 11) | (qi << 19);
-                entry = JTK_PL_HARD | (qi << JTK_PL_QI_SHIFT) | (uint32_t)s;
-            }
-            plist[k] = entry;
-        }
     }
     __syncthreads();
     // the tile's slices of its queue shards are claimed with one returning atomic per bin
