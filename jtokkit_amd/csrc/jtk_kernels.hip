@@ -373,8 +373,6 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
     __shared__ uint16_t s_plist[T + 1];
     __shared__ uint64_t s_pm[TW];
-    __shared__ uint32_t s_cnt[TW];
-    __shared__ uint32_t s_pre[TW + 1];
     __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
     __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
@@ -397,7 +395,6 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         // the end sentinel (bit n) is not a piece
         if ((n >> 6) == wd) m &= ~(1ull << (n & 63));
         s_pm[tid] = m;
-        s_cnt[tid] = (uint32_t)__popcll(m);
     }
     if (tid < JTK_NBINS) s_qn[tid] = 0;
     if (tid == 0) s_nhard = 0;
@@ -410,12 +407,18 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         s_next_after = (pos < 0) ? n : pos;
     }
     __syncthreads();
-    if (wv == 0) wave_scan_small(s_cnt, s_pre, TW);
-    __syncthreads();
-    const int np = (int)s_pre[TW];
-    for (int wd = wv; wd < TW; wd += 4) {
-        const uint64_t m = s_pm[wd];
-        if ((m >> lane) & 1ull) s_plist[s_pre[wd] + __popcll(m & lanemask_lt())] = (uint16_t)(wd * 64 + lane);
+    // piece list: every wave scans the 32 word counts itself (lane l: word l), then compacts its share of the words
+    int np;
+    {
+        const uint32_t c = lane < TW ? (uint32_t)__popcll(s_pm[lane]) : 0u;
+        const uint32_t inc = wave_incl_scan(c);
+        np = (int)(uint32_t)__shfl((int)inc, 63);
+        const uint32_t pre = inc - c;
+        for (int wd = wv; wd < TW; wd += 4) {
+            const uint64_t m = s_pm[wd];
+            const uint32_t base = (uint32_t)__shfl((int)pre, wd);
+            if ((m >> lane) & 1ull) s_plist[base + __popcll(m & lanemask_lt())] = (uint16_t)(wd * 64 + lane);
+        }
     }
     __syncthreads();
 
