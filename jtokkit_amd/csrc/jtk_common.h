@@ -138,21 +138,6 @@ struct JtkTok8Table {
     const JtkTok8Slot* slots;
     uint32_t bits;   // number of slots (the field keeps its old name)
 };
-JTK_HD uint32_t jtk_tok8_hash(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) {
-    uint32_t h = lo * 0x9E3779B1u + (hi ^ (len << 27)) * 0x85EBCA77u;
-    h ^= h >> 16;
-    h *= 0x2C1B3C6Du;
-    h ^= h >> 13;
-    return jtk_reduce32(h, nslots);
-}
-JTK_HD uint32_t jtk_tok8_hash2(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) {
-    uint32_t h = (lo ^ (len << 29)) * 0xC2B2AE3Du + hi * 0x27D4EB2Fu + 0x9E3779B1u;
-    h ^= h >> 15;
-    h *= 0x85EBCA77u;
-    h ^= h >> 13;
-    return jtk_reduce32(h, nslots);
-}
-
 // ---- whole-piece table for pieces of 9..16 bytes ------------------------------------------------------
 // Same shortcut (GptBytePairEncoding.java:81-83) for the longer words of ordinary text, which would otherwise
 // cost the most merge steps.  Key = 16 bytes little-endian in k[4], zero padded, plus the length.  32-byte slots,
@@ -179,6 +164,11 @@ JTK_HD uint32_t jtk_tok16_hash2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t 
     h ^= h >> 13;
     return jtk_reduce32(h, nslots);
 }
+
+// the <= 8-byte table hashes the same way (upper key words zero), so the device computes one hash per choice whatever
+// the piece's length
+JTK_HD uint32_t jtk_tok8_hash(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) { return jtk_tok16_hash(lo, hi, 0u, 0u, len, nslots); }
+JTK_HD uint32_t jtk_tok8_hash2(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) { return jtk_tok16_hash2(lo, hi, 0u, 0u, len, nslots); }
 
 // ---- Unicode class lookup ----------------------------------------------------------------------------
 struct JtkUcTables {

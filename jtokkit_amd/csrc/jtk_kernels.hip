@@ -457,19 +457,15 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
 #pragma unroll
             for (int q = 0; q < 4; q++) k[q] &= (len >= 4u * q + 4u) ? ~0u : (len > 4u * q ? part : 0u);
             pr.k0 = k[0]; pr.k1 = k[1]; pr.k2 = k[2]; pr.k3 = k[3];
-            const uint4 *pa, *pb;
-            const uint2 *qa, *qb;
-            if (len <= 8) {
-                pa = reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash(k[0], k[1], len, t.tok8.bits)]);
-                pb = reinterpret_cast<const uint4*>(&t8[jtk_tok8_hash2(k[0], k[1], len, t.tok8.bits)]);
-                qa = reinterpret_cast<const uint2*>(pa) + 1;           // (id, len) of the 16-byte slot
-                qb = reinterpret_cast<const uint2*>(pb) + 1;
-            } else {
-                pa = reinterpret_cast<const uint4*>(&t16[jtk_tok16_hash(k[0], k[1], k[2], k[3], len, t.tok16.n)]);
-                pb = reinterpret_cast<const uint4*>(&t16[jtk_tok16_hash2(k[0], k[1], k[2], k[3], len, t.tok16.n)]);
-                qa = reinterpret_cast<const uint2*>(pa + 1);           // (id, len) after the 16-byte key
-                qb = reinterpret_cast<const uint2*>(pb + 1);
-            }
+            // one hash per choice for both tables; only base, slot size and slot count depend on the length
+            const bool small = len <= 8u;
+            const uint32_t nsl = small ? t.tok8.bits : t.tok16.n;
+            const uint8_t* base = small ? reinterpret_cast<const uint8_t*>(t8) : reinterpret_cast<const uint8_t*>(t16);
+            const uint32_t shift = small ? 4u : 5u, moff = small ? 8u : 16u;          // slot bytes, offset of (id, len)
+            const uint8_t* sa = base + ((uint64_t)jtk_tok16_hash(k[0], k[1], k[2], k[3], len, nsl) << shift);
+            const uint8_t* sb = base + ((uint64_t)jtk_tok16_hash2(k[0], k[1], k[2], k[3], len, nsl) << shift);
+            const uint4 *pa = reinterpret_cast<const uint4*>(sa), *pb = reinterpret_cast<const uint4*>(sb);
+            const uint2 *qa = reinterpret_cast<const uint2*>(sa + moff), *qb = reinterpret_cast<const uint2*>(sb + moff);
             pr.ka = *pa; pr.kb = *pb; pr.ma = *qa; pr.mb = *qb;
         }
     };
@@ -480,13 +476,10 @@ __global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTable
         int bin = -1;
         if (len <= 16) {
             uint32_t id = JTK_RANK_NONE;
-            if (len <= 8) {
-                if (pr.ma.y == (uint32_t)len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1) id = pr.ma.x;
-                else if (pr.mb.y == (uint32_t)len && pr.kb.x == pr.k0 && pr.kb.y == pr.k1) id = pr.mb.x;
-            } else {
-                if (pr.ma.y == (uint32_t)len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1 && pr.ka.z == pr.k2 && pr.ka.w == pr.k3) id = pr.ma.x;
-                else if (pr.mb.y == (uint32_t)len && pr.kb.x == pr.k0 && pr.kb.y == pr.k1 && pr.kb.z == pr.k2 && pr.kb.w == pr.k3) id = pr.mb.x;
-            }
+            const bool small = len <= 8;                              // tok8 slots hold (lo, hi, id, len): compare two key words
+            const bool hit_a = pr.ma.y == (uint32_t)len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1 && (small || (pr.ka.z == pr.k2 && pr.ka.w == pr.k3));
+            const bool hit_b = pr.mb.y == (uint32_t)len && pr.kb.x == pr.k0 && pr.kb.y == pr.k1 && (small || (pr.kb.z == pr.k2 && pr.kb.w == pr.k3));
+            if (hit_a) id = pr.ma.x; else if (hit_b) id = pr.mb.x;
             if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT); else bin = 0;
         } else if (len <= 32) bin = 1;
         else if (len <= 64) bin = 2;
