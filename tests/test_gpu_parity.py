@@ -404,3 +404,28 @@ def test_custom_encoding(jt, kind):
     with pytest.raises(jt.UnsupportedOperationError):
         enc.encode("a <|endoftext|> b")
     enc.close()
+
+
+def test_large_batch_1gb(jt):
+    """A 1 GB batch (cfg-3-shaped mixed UTF-8, 250k docs x ~4 KB): 64-bit positions everywhere, > 2^31 scratch bytes.
+    Size-independent properties: device decode of the tokens reproduces the input exactly with the documents' byte
+    offsets, token offsets are monotone; a document sample equals the oracle."""
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = corpus.mixed(250000, seed=31)
+    assert len(text) > 900e6
+    b = enc.new_batch()
+    nt = b.encode_host(text, doc_off, ordinary=True)
+    res = b.fetch()
+    assert (res.status == 0).all() and nt == len(res.tokens)
+    assert (np.diff(res.tok_off) >= 0).all() and res.tok_off[-1] == nt
+    nb = b.decode_host(res.tokens, res.tok_off)
+    out, byte_off, status = b.decode_fetch()
+    assert nb == len(text) and (status == 0).all() and np.array_equal(byte_off, doc_off)
+    assert np.array_equal(out, text)
+    rng = np.random.default_rng(1)
+    for d in rng.choice(len(doc_off) - 1, 300, replace=False).tolist() + [0, len(doc_off) - 2]:
+        doc = text[doc_off[d]:doc_off[d + 1]].tobytes()
+        assert res.doc(d).tolist() == o.encode_ordinary(doc), d
+    b.close()
