@@ -106,6 +106,9 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
 int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* d_doc_off, int64_t n_docs,
                             int64_t n_bytes, uint32_t flags, void* stream_or_null, int64_t* n_tokens);
 
+/* The batch's own HIP stream (a hipStream_t), e.g. to order a caller's work after a non-synchronising encode. */
+void* jtk_batch_stream(jtk_batch* b);
+
 /* Synchronises and reports the totals of the last encode. */
 int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* worst_status);
 

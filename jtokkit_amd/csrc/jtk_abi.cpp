@@ -42,8 +42,9 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-constexpr int N_STAGES = 6;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge", "pack"};
+constexpr int N_STAGES = 8;
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge",
+                                           "tile_counts_scan", "pack", "doc_offsets"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -103,7 +104,9 @@ static int finish_giants(jtk_batch* b) {
     HIP_TRY(hipMemcpyAsync(b->giant_off.p, off.data(), (ng + 1) * 8, hipMemcpyHostToDevice, s));
     jtk_launch_bpe_merge_giant(b->work, b->enc->dt, ng, (const int64_t*)b->giant_off.p, (uint32_t*)b->giant_scratch.p, s);
     HIP_TRY(hipMemsetAsync(b->work.chunk_sum, 0, ((size_t)b->work.n_tiles / 4096 + 1) * 8, s));
+    jtk_launch_tile_counts_scan(b->work, s);
     jtk_launch_pack(b->work, s);
+    jtk_launch_doc_offsets(b->work, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->host_result, b->work.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -374,7 +377,13 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     jtk_launch_bpe_merge(w, enc->dt, s);
     end(s);
     begin(s);
+    jtk_launch_tile_counts_scan(w, s);
+    end(s);
+    begin(s);
     jtk_launch_pack(w, s);
+    end(s);
+    begin(s);
+    jtk_launch_doc_offsets(w, s);
     end(s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->host_result, w.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
@@ -413,6 +422,8 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
     if (n_tokens) *n_tokens = nt;
     return JTK_OK;
 }
+
+void* jtk_batch_stream(jtk_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* worst_status) {
     if (!b || !b->have_result) return fail(JTK_ERR_INVALID_ARGUMENT, "no encode has run on this batch");

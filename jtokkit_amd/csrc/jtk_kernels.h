@@ -160,6 +160,8 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // pieces of up to 8192 bytes
 void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
                                 uint32_t* scratch, hipStream_t s);
+void jtk_launch_tile_counts_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);
+void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s);
 
 #endif

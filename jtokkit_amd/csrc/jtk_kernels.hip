@@ -1347,10 +1347,14 @@ void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint
                                 uint32_t* scratch, hipStream_t s) {
     if (n_giant) hipLaunchKernelGGL(k_bpe_merge_giant, dim3(n_giant), dim3(256), 0, s, w, t, scratch_off, scratch);
 }
-void jtk_launch_pack(const JtkWork& w, hipStream_t s) {
+void jtk_launch_tile_counts_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 63) / 64)), dim3(1024), 0, s, w);
     hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((w.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK)), dim3(1024), 0, s, w);
+}
+void jtk_launch_pack(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)w.n_tiles), dim3(64), 0, s, w);
+}
+void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s) {
     const int64_t n = w.n_docs + 1;
     hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w);
 }

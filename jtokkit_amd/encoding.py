@@ -103,6 +103,10 @@ class Batch:
                                                C.byref(nt) if sync else None))
         return nt.value if sync else None
 
+    def stream(self):
+        """The batch's own HIP stream handle (int)."""
+        return N.lib().jtk_batch_stream(self._h)
+
     def result(self):
         nt, nd, ws = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         _check(N.lib().jtk_batch_result(self._h, C.byref(nt), C.byref(nd), C.byref(ws)))

@@ -31,12 +31,17 @@ def local_shard(text, doc_off, rank, world_size):
 
 
 def gather_shard_totals(n_tokens_local, group=None, device=None):
-    """All-gather of one int64 per rank; returns (totals[world], base offset of this rank)."""
+    """All-gather of one int64 per rank; returns (totals[world], base offset of this rank).
+    n_tokens_local: an int, or a 1-element device tensor (e.g. the last entry of the shard's token offsets)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    mine = torch.tensor([int(n_tokens_local)], dtype=torch.int64, device=device)
+    if isinstance(n_tokens_local, torch.Tensor):          # already on the device: no host round trip
+        mine = n_tokens_local.reshape(1).to(dtype=torch.int64).clone()
+        device = mine.device
+    else:
+        mine = torch.tensor([int(n_tokens_local)], dtype=torch.int64, device=device)
     totals = torch.zeros(world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(totals, mine, group=group)
     base = totals[:rank].sum()
