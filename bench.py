@@ -87,10 +87,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    rehearsal = os.environ.get("JTK_BENCH_REHEARSAL") == "1"     # all ranks on GPU 0 over gloo: exercises the N > 1 code on a one-GPU box
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     import jtokkit_amd
     from jtokkit_amd import corpus, sharding
 
@@ -168,7 +174,8 @@ def main():
                 serial_ms[name] = serial_ms.get(name, 0.0) + v / 5
 
     # max over ranks, sum of bytes
-    stats = torch.tensor([dt, float(n_bytes), float(nt), float(n_docs)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([dt, float(n_bytes), float(nt), float(n_docs)], dtype=torch.float64,
+                         device=torch.device("cpu") if rehearsal else dev)
     if world > 1:
         allst = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(allst, stats)

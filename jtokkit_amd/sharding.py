@@ -42,8 +42,13 @@ def gather_shard_totals(n_tokens_local, group=None, device=None):
         device = mine.device
     else:
         mine = torch.tensor([int(n_tokens_local)], dtype=torch.int64, device=device)
-    totals = torch.zeros(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(totals, mine, group=group)
+    if dist.get_backend(group) == "gloo":                 # CPU rehearsal of the multi-GPU path (tests, one-GPU boxes)
+        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, mine.cpu(), group=group)
+        totals = torch.cat(parts).to(mine.device)
+    else:
+        totals = torch.zeros(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(totals, mine, group=group)
     base = totals[:rank].sum()
     return totals, base
 
