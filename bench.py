@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--encoding", default="cl100k_base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--serial-pass", action="store_true",
+                    help="after the timed region, 5 more steps strictly one after the other: per-kernel times without overlap")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight, each on its own HIP stream with its own scratch (1 = strictly one after the other)")
     args = ap.parse_args()
@@ -164,9 +166,9 @@ def main():
     dt = time.perf_counter() - t0
     nt = batches[0].result()[0]
 
-    # after the clock: a few steps strictly one after the other, for per-kernel times without overlap (reported beside)
+    # --serial-pass, after the clock: a few steps strictly one after the other, for per-kernel times without overlap
     serial_ms = {}
-    if n_fl > 1:
+    if n_fl > 1 and args.serial_pass:
         for _ in range(5):
             batches[0].encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=True,
                                      stream=streams[0].cuda_stream, sync=True)
