@@ -600,6 +600,7 @@ struct MergeLds {
     const uint16_t* bpcum;
     const uint32_t* brank;
     uint32_t* next;          // [JTK_NBINS] queue positions handed out, one counter per bin
+    const uint32_t* count;   // [JTK_NBINS + 2] entries in this workgroup's shard of each bin's queue; mid and long list lengths
 };
 
 // One length bin: the first THREADS lanes of the workgroup drain this workgroup's chunks of the bin's queue shard.
@@ -615,7 +616,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
     // dense queue shard `shard`; this workgroup takes chunks kq, kq + K, kq + 2K, ... of it
     const int shard = blockIdx.x % JTK_Q_SHARDS;
     const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
-    const uint32_t count = w.q_count[BIN * JTK_Q_SHARDS + shard];
+    const uint32_t count = L.count[BIN];
     if ((uint64_t)kq * M_CHUNK >= count) return;
     uint64_t* const queue = w.q[BIN] + (int64_t)shard * w.q_cap[BIN];     // entries are read in aligned pairs
 
@@ -941,29 +942,36 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     __shared__ uint16_t s_bpcum[1024];
     __shared__ uint32_t s_brank[256];
     __shared__ uint32_t s_next[JTK_NBINS];
+    __shared__ uint32_t s_count[JTK_NBINS + 2];
     const int tid = threadIdx.x;
     for (int i = tid; i < 1024; i += 1024) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += 1024) s_bpranks[i] = t.bp.ranks[i];
     for (int i = tid; i < 256; i += 1024) s_brank[i] = t.byte_rank[i];
-    if (tid < JTK_NBINS) s_next[tid] = 0;
+    if (tid < JTK_NBINS) {
+        s_next[tid] = 0;
+        s_count[tid] = w.q_count[tid * JTK_Q_SHARDS + blockIdx.x % JTK_Q_SHARDS];
+    }
+    if (tid == JTK_NBINS) s_count[JTK_NBINS] = *w.mid_count;
+    if (tid == JTK_NBINS + 1) s_count[JTK_NBINS + 1] = *w.long_count;
     __syncthreads();
-    const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next};
+    const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
+    // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
     merge_bin<16, 1024, 0>(w, t, L);
-    __syncthreads();
-    merge_bin<32, 512, 1>(w, t, L);
-    __syncthreads();
-    merge_bin<64, 256, 2>(w, t, L);
-    __syncthreads();
-    merge_bin<128, 128, 3>(w, t, L);
-    __syncthreads();
-    merge_bin<256, 64, 4>(w, t, L);
-    __syncthreads();
+    if (s_count[1]) { __syncthreads(); merge_bin<32, 512, 1>(w, t, L); }
+    if (s_count[2]) { __syncthreads(); merge_bin<64, 256, 2>(w, t, L); }
+    if (s_count[3]) { __syncthreads(); merge_bin<128, 128, 3>(w, t, L); }
+    if (s_count[4]) { __syncthreads(); merge_bin<256, 64, 4>(w, t, L); }
     // pieces of 257..512 bytes: every wave of the grid takes pieces, parts in its own 2 x 512 words
     const uint32_t wv = (uint32_t)tid >> 6;
-    merge_long<JTK_MID_CAP>(w, t, s_id + wv * JTK_MID_CAP, s_rk + wv * JTK_MID_CAP, blockIdx.x * 16u + wv, gridDim.x * 16u);
-    __syncthreads();
-    // pieces of 513..8192 bytes: one wave per workgroup, parts in 2 x 8192 words
-    if (wv == 0) merge_long<JTK_LONG_CAP>(w, t, s_id, s_rk, blockIdx.x, gridDim.x);
+    if (s_count[JTK_NBINS]) {
+        __syncthreads();
+        merge_long<JTK_MID_CAP>(w, t, s_id + wv * JTK_MID_CAP, s_rk + wv * JTK_MID_CAP, blockIdx.x * 16u + wv, gridDim.x * 16u);
+    }
+    // pieces of 513..8192 bytes (and the listing of longer ones): one wave per workgroup, parts in 2 x 8192 words
+    if (s_count[JTK_NBINS + 1]) {
+        __syncthreads();
+        if (wv == 0) merge_long<JTK_LONG_CAP>(w, t, s_id, s_rk, blockIdx.x, gridDim.x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
