@@ -194,6 +194,8 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     memset(&dt, 0, sizeof(dt));
     dt.uc.stage1 = (const uint8_t*)enc->uc1.p;
     dt.uc.stage2 = (const uint32_t*)enc->uc2.p;
+    dt.uc_stage1_len = JTK_UC_STAGE1_LEN;
+    dt.uc_stage2_words = JTK_UC_STAGE2_WORDS;
     dt.byte_rank = (const uint32_t*)enc->brank.p;
     dt.pairs.buckets = (const JtkPairBucket*)enc->pairs.p;
     dt.pairs.bits = enc->host.pair_bits;

@@ -103,7 +103,11 @@ JTK_HD void jtk_block_fix_nonascii(const Txt& txt, const JtkUcTables& uc, int64_
         if (b0 < 0xE0u) { cp = ((b0 & 0x1Fu) << 6) | (txt.byte(p + 1) & 0x3Fu); n = 2; }
         else if (b0 < 0xF0u) { cp = ((b0 & 0x0Fu) << 12) | ((txt.byte(p + 1) & 0x3Fu) << 6) | (txt.byte(p + 2) & 0x3Fu); n = 3; }
         else { cp = ((b0 & 0x07u) << 18) | ((txt.byte(p + 1) & 0x3Fu) << 12) | ((txt.byte(p + 2) & 0x3Fu) << 6) | (txt.byte(p + 3) & 0x3Fu); n = 4; }
-        const uint32_t cls = jtk_class_of_cp(uc, cp);
+        // CJK ideographs (incl. extension A) and Hangul syllables are letters throughout (Unicode 13: U+3400-4DBF,
+        // U+4E00-9FFC, U+AC00-D7A3 are all Lo); everything else goes through the two-stage table
+        uint32_t cls;
+        if ((cp - 0x3400u) <= (0x4DBFu - 0x3400u) || (cp - 0x4E00u) <= (0x9FFCu - 0x4E00u) || (cp - 0xAC00u) <= (0xD7A3u - 0xAC00u)) cls = JTK_CLS_L;
+        else cls = jtk_class_of_cp(uc, cp);
         // the character's bytes: the lead and the continuation bytes that directly follow it (at most n-1)
         uint64_t bytes = 1ull << j;
         for (uint32_t q = 1; q < n; q++) {

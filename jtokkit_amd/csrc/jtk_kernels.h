@@ -39,8 +39,12 @@
 #define JTK_MAX_SPECIALS 8
 #define JTK_SPECIAL_MAXLEN 32
 
+#define JTK_UC_LDS_STAGE1 4352    // capacity of the LDS copy of the Unicode class table (pretok_split)
+#define JTK_UC_LDS_STAGE2 2048
+
 struct JtkDeviceTables {
     JtkUcTables uc;
+    uint32_t uc_stage1_len, uc_stage2_words;
     const uint32_t* byte_rank;   // [256]
     JtkPairTable pairs;
     JtkTok8Table tok8;

@@ -178,6 +178,15 @@ struct GlobalText {
     __device__ uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
 };
 
+// The lane's own 64-byte block (and the first bytes of the next lane's) from the LDS copy, [dword][lane].
+struct LdsBlockText {
+    const uint32_t* blk; int tid; int64_t p0;
+    __device__ uint32_t byte(int64_t p) const {
+        const uint32_t rel = (uint32_t)(p - p0);                       // 0 .. 66
+        return (blk[((rel >> 2) & 15u) * 256u + (uint32_t)tid + (rel >> 6)] >> (8u * (rel & 3u))) & 255u;
+    }
+};
+
 // Unbounded window over global memory for the rare positions that need a run walk (exact).
 struct SlowWin {
     typedef int64_t idx_t;
@@ -207,11 +216,16 @@ template <int KIND>
 __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables t) {
     __shared__ uint16_t s_codes[256];          // per-byte flag codes (jtk_byte_code)
     __shared__ uint32_t s_pin[2048];           // byte pairs that occur inside some table entry
+    __shared__ uint32_t s_blk[16 * 256 + 4];   // the lanes' blocks, [dword][lane] (staged only for text outside ASCII)
+    __shared__ __attribute__((aligned(4))) uint8_t s_uc1[JTK_UC_LDS_STAGE1];
+    __shared__ uint32_t s_uc2[JTK_UC_LDS_STAGE2];
+    __shared__ uint32_t s_uc_ready;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
     const int64_t n = w.n_bytes;
     s_codes[tid] = (uint16_t)jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
+    if (tid == 0) s_uc_ready = 0;
     for (int i = tid; i < 2048; i += 256) s_pin[i] = t.pair_in_token[i];
     __syncthreads();
 
@@ -234,9 +248,31 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
     uint64_t lead;
     jtk_block_masks_ascii(d, s_codes, cu, lead);
     {
-        const GlobalText gt{w.text, n};
-        uint32_t spill;
-        jtk_block_fix_nonascii(gt, t.uc, p0, lead, cu, spill);
+        // Characters outside ASCII are decoded and classified one by one.  Only workgroups that have any stage what
+        // that needs in LDS -- the Unicode class table (12 KB) and each lane's 64 bytes -- so that the per-character
+        // chain is LDS reads, not global loads (the kernel runs at 2 waves per SIMD: nothing hides a global latency).
+        uint32_t spill = JTK_CLS_O;
+        const bool lds_ok = t.uc_stage1_len <= JTK_UC_LDS_STAGE1 && t.uc_stage2_words <= JTK_UC_LDS_STAGE2;
+        if (__ballot(lead != 0)) {                                    // per wave: no workgroup barrier on the ASCII path
+            if (lds_ok) {
+                // the first wave that needs the table copies it; a wave that does not see the flag yet copies it again
+                // (same values: a benign race), so no barrier is needed
+                if (*(volatile uint32_t*)&s_uc_ready == 0u) {
+                    for (uint32_t i = lane; i < t.uc_stage1_len / 4; i += 64) reinterpret_cast<uint32_t*>(s_uc1)[i] = reinterpret_cast<const uint32_t*>(t.uc.stage1)[i];
+                    for (uint32_t i = lane; i < t.uc_stage2_words; i += 64) s_uc2[i] = t.uc.stage2[i];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) s_blk[q * 256 + tid] = d[q];
+                wave_lds_fence();
+                if (lane == 0) *(volatile uint32_t*)&s_uc_ready = 1u;
+                const LdsBlockText lt{s_blk, tid, p0};
+                const JtkUcTables ucl{s_uc1, s_uc2};
+                jtk_block_fix_nonascii(lt, ucl, p0, lead, cu, spill);
+            } else {
+                const GlobalText gt{w.text, n};
+                jtk_block_fix_nonascii(gt, t.uc, p0, lead, cu, spill);
+            }
+        }
         uint32_t prev_spill = (uint32_t)__shfl_up((int)spill, 1);
         if (lane == 0) prev_spill = JTK_CLS_O;
         jtk_block_apply_spill(cu, prev_spill);
