@@ -32,7 +32,7 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16):
+def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16, ordinary=False):
     """Oracle (CPU restatement of GptBytePairEncoding.encode, kind "port") on the host cores, on a
     bounded prefix of the same workload: one task per document on a fixed pool, as the reference's JMH
     harness does (AbstractMultiThreadedBenchmark.java:35-45)."""
@@ -45,7 +45,7 @@ def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16):
 
     def run(nd, threads):
         t0 = time.perf_counter()
-        enc.encode_batch(text, doc_off[:nd + 1], threads=threads, want_tokens=False)
+        enc.encode_batch(text, doc_off[:nd + 1], threads=threads, ordinary=ordinary, want_tokens=False)
         return time.perf_counter() - t0
 
     probe = min(n_docs, 400)
@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--encoding", default="cl100k_base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--ordinary", action="store_true",
+                    help="time encodeOrdinary() instead of encode() (skips the special-token check of GptBytePairEncoding.java:52-56)")
     ap.add_argument("--serial-pass", action="store_true",
                     help="after the timed region, 5 more steps strictly one after the other: per-kernel times without overlap")
     ap.add_argument("--inflight", type=int, default=2,
@@ -127,7 +129,7 @@ def main():
     def step(i):
         b, st = batches[i % n_fl], streams[i % n_fl]
         with torch.cuda.stream(st):
-            b.encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=True, stream=st.cuda_stream, sync=False)
+            b.encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=args.ordinary, stream=st.cuda_stream, sync=False)
             if world > 1:
                 # shard token totals -> every rank; exclusive prefix = this shard's global token offset (same stream)
                 _, off_ptr, _ = b.device_result()
@@ -170,7 +172,7 @@ def main():
     serial_ms = {}
     if n_fl > 1 and args.serial_pass:
         for _ in range(5):
-            batches[0].encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=True,
+            batches[0].encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=args.ordinary,
                                      stream=streams[0].cuda_stream, sync=True)
             for name, v in batches[0].kernel_times().items():
                 serial_ms[name] = serial_ms.get(name, 0.0) + v / 5
@@ -230,7 +232,7 @@ def main():
             out["roofline_serial"] = {"kernel": dom_kernel, "achieved": round(a, 2), "frac": round(a / HBM_PEAK_GBS, 5),
                                       "avg_launch_ms": round(serial_ms[dom], 4)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(text, doc_off, max_threads=args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(text, doc_off, max_threads=args.cpu_threads, ordinary=args.ordinary)
         print(json.dumps(out), flush=True)
     for b in batches:
         b.close()
