@@ -43,7 +43,7 @@ struct DevBuf {
 };
 
 constexpr int N_STAGES = 8;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "special_check", "pretok_split", "piece_resolve", "bpe_merge",
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "piece_resolve", "bpe_merge",
                                            "tile_counts_scan", "pack", "doc_offsets"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -295,6 +295,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.n_docs = n_docs;
     w.n_words = (n_bytes + 1 + 63) / 64 + 2;
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
+    w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
 
     // zeroed per encode: docmask | status | result + list counters | queue counters | chunk sums | tile_extra
     const size_t mask_bytes = (size_t)w.n_words * 8;
@@ -365,8 +366,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     HIP_TRY(hipMemsetAsync(b->zeroed.p, 0, zero_bytes, s));
     jtk_launch_mark_docs(w, s);
     end(s);
-    begin(s);                                                   // special_check (+ utf8 validation)
-    if (!(flags & JTK_ENCODE_ORDINARY)) jtk_launch_special_check(w, enc->dt, s);
+    begin(s);                                                   // optional UTF-8 validation (the special-token check rides in pretok_split)
     if (flags & JTK_ENCODE_VALIDATE_UTF8) jtk_launch_validate_utf8(w, s);
     end(s);
     begin(s);

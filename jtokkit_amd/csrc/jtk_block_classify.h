@@ -18,7 +18,8 @@
 enum : uint32_t {
     JTK_F_L = 1u << 0, JTK_F_N = 1u << 1, JTK_F_W = 1u << 2, JTK_F_NL = 1u << 3, JTK_F_SP = 1u << 4, JTK_F_AP = 1u << 5,
     JTK_F_CONT = 1u << 6, JTK_F_LEAD = 1u << 7,          // LEAD: first byte of a non-ASCII character
-    JTK_F_S1 = 1u << 8, JTK_F_RV = 1u << 9, JTK_F_E = 1u << 10, JTK_F_LL = 1u << 11, JTK_F_C5 = 1u << 12, JTK_F_BF = 1u << 13
+    JTK_F_S1 = 1u << 8, JTK_F_RV = 1u << 9, JTK_F_E = 1u << 10, JTK_F_LL = 1u << 11, JTK_F_C5 = 1u << 12, JTK_F_BF = 1u << 13,
+    JTK_F_LT = 1u << 14                                   // '<': where a special-token literal can start
 };
 
 JTK_HD uint32_t jtk_byte_code(uint32_t b, bool case_insensitive) {
@@ -31,6 +32,7 @@ JTK_HD uint32_t jtk_byte_code(uint32_t b, bool case_insensitive) {
         if (b == '\r' || b == '\n') c |= JTK_F_NL;
         if (b == 0x20u) c |= JTK_F_SP;
         if (b == '\'') c |= JTK_F_AP;
+        if (b == '<') c |= JTK_F_LT;
         const uint32_t f = (case_insensitive && (b - 'A') < 26u) ? (b | 0x20u) : b;
         if (f == 's' || f == 't' || f == 'm' || f == 'd') c |= JTK_F_S1;
         if (f == 'r' || f == 'v') c |= JTK_F_RV;
@@ -57,7 +59,7 @@ JTK_HD uint64_t jtk_transpose8x8(uint64_t x) {
 // Fills the table-derived part of the masks (class bits of non-ASCII characters are still 0).
 // lead_out: mask of non-ASCII lead bytes.
 template <class CodeTab>
-JTK_HD void jtk_block_masks_ascii(const uint32_t (&d)[16], const CodeTab& codes, JtkBlk& k, uint64_t& lead_out) {
+JTK_HD void jtk_block_masks_ascii(const uint32_t (&d)[16], const CodeTab& codes, JtkBlk& k, uint64_t& lead_out, uint64_t& lt_out) {
     uint64_t lo_m[8], hi_m[8];
 #pragma unroll
     for (int f = 0; f < 8; f++) { lo_m[f] = 0; hi_m[f] = 0; }
@@ -75,12 +77,18 @@ JTK_HD void jtk_block_masks_ascii(const uint32_t (&d)[16], const CodeTab& codes,
 #pragma unroll
         for (int f = 0; f < 8; f++) {
             lo_m[f] |= ((yl >> (8 * f)) & 255ull) << (8 * g);
-            if (f < 6) hi_m[f] |= ((yh >> (8 * f)) & 255ull) << (8 * g);
+            if (f < 7) hi_m[f] |= ((yh >> (8 * f)) & 255ull) << (8 * g);
         }
     }
     k.L = lo_m[0]; k.N = lo_m[1]; k.W = lo_m[2]; k.NL = lo_m[3]; k.SP = lo_m[4]; k.AP = lo_m[5]; k.CONT = lo_m[6];
     lead_out = lo_m[7];
     k.S1 = hi_m[0]; k.RV = hi_m[1]; k.E = hi_m[2]; k.LL = hi_m[3]; k.C5 = hi_m[4]; k.BF = hi_m[5];
+    lt_out = hi_m[6];
+}
+template <class CodeTab>
+JTK_HD void jtk_block_masks_ascii(const uint32_t (&d)[16], const CodeTab& codes, JtkBlk& k, uint64_t& lead_out) {
+    uint64_t lt;
+    jtk_block_masks_ascii(d, codes, k, lead_out, lt);
 }
 
 // Non-ASCII characters that START in this block: decode (Txt gives byte(p) for any p), classify, and

@@ -78,8 +78,23 @@ __device__ int64_t find_doc(const int64_t* doc_off, int64_t n_docs, int64_t p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// special_check: flag documents that contain a special-token literal (all literals start with "<|")
+// special_check: flag documents that contain a special-token literal (all literals start with "<|").
+// The exact test at one position; pretok_split calls it for the '<' bytes it sees (k_special_check is the
+// stand-alone form of the same test).
 // ---------------------------------------------------------------------------------------------------
+__device__ void special_check_at(const JtkWork& w, const JtkDeviceTables& t, int64_t p) {
+    if (p < 0 || p + 1 >= w.n_bytes || w.text[p] != '<' || w.text[p + 1] != '|') return;
+    for (int s = 0; s < t.n_specials; s++) {
+        const int len = t.special_len[s];
+        if (p + len > w.n_bytes) continue;
+        bool eq = true;
+        for (int j = 0; j < len && eq; j++) eq = (w.text[p + j] == t.special[s][j]);
+        if (!eq) continue;
+        const int64_t d = find_doc(w.doc_off, w.n_docs, p);
+        if (d >= 0 && p + len <= w.doc_off[d + 1]) atomicMin(&w.status[d], -2 /* JTK_ERR_UNSUPPORTED_SPECIAL */);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_special_check(JtkWork w, JtkDeviceTables t) {
     const int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (base >= w.n_bytes) return;
@@ -103,19 +118,7 @@ __global__ void __launch_bounds__(256) k_special_check(JtkWork w, JtkDeviceTable
         any |= ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
     }
     if (!any) return;
-    for (int k = 0; k < 16; k++) {
-        const int64_t p = base + k;
-        if (p + 1 >= w.n_bytes || w.text[p] != '<' || w.text[p + 1] != '|') continue;
-        for (int s = 0; s < t.n_specials; s++) {
-            const int len = t.special_len[s];
-            if (p + len > w.n_bytes) continue;
-            bool eq = true;
-            for (int j = 0; j < len && eq; j++) eq = (w.text[p + j] == t.special[s][j]);
-            if (!eq) continue;
-            const int64_t d = find_doc(w.doc_off, w.n_docs, p);
-            if (d >= 0 && p + len <= w.doc_off[d + 1]) atomicMin(&w.status[d], -2 /* JTK_ERR_UNSUPPORTED_SPECIAL */);
-        }
-    }
+    for (int k = 0; k < 16; k++) special_check_at(w, t, base + k);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -245,8 +248,16 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
         d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
     }
     JtkBlk cu;
-    uint64_t lead;
-    jtk_block_masks_ascii(d, s_codes, cu, lead);
+    uint64_t lead, lt;
+    jtk_block_masks_ascii(d, s_codes, cu, lead, lt);
+    // encode(): the special-token check of GptBytePairEncoding.java:52-56 rides along -- every '<' of the lanes that emit
+    if (w.check_special && lane >= 1 && lane <= SPW) {
+        for (uint64_t m = lt; m;) {
+            const int j = jtk_ctz64(m);
+            m &= m - 1;
+            special_check_at(w, t, p0 + j);
+        }
+    }
     {
         // Characters outside ASCII are decoded and classified one by one.  Only workgroups that have any stage what
         // that needs in LDS -- the Unicode class table (12 KB) and each lane's 64 bytes -- so that the per-character
