@@ -68,6 +68,24 @@ public:
         check(jtk_batch_fetch(batch_, tokens.data(), nt, tokOff.data(), status.data()));
     }
 
+    // batch encode(text, maxTokens): after encodeBatch, how many of each document's tokens survive the limit (incl. the
+    // reference's back-off to a code-point boundary) and EncodingResult.isTruncated() per document
+    void truncateBatch(int64_t maxTokens, std::vector<int64_t>& kept, std::vector<uint8_t>& truncated, size_t nDocs) {
+        check(jtk_batch_truncate(batch_, maxTokens));
+        kept.resize(nDocs); truncated.resize(nDocs);
+        check(jtk_batch_fetch_truncated(batch_, kept.data(), truncated.data()));
+    }
+
+    // batch decodeBytes: token lists back to back in `ids`, n+1 offsets -> bytes back to back + n+1 byte offsets + status
+    void decodeBatch(const int32_t* ids, const std::vector<int64_t>& seqOff, std::string& bytes,
+                     std::vector<int64_t>& byteOff, std::vector<int32_t>& status) {
+        int64_t nb = 0;
+        const int64_t n = (int64_t)seqOff.size() - 1;
+        check(jtk_batch_decode(batch_, ids, seqOff.data(), n, &nb));
+        bytes.resize((size_t)nb); byteOff.resize((size_t)n + 1); status.resize((size_t)n);
+        check(jtk_batch_decode_fetch(batch_, (uint8_t*)&bytes[0], nb, byteOff.data(), status.data()));
+    }
+
 private:
     EncodingResult run(const std::string& text, uint32_t flags, int64_t maxTokens) {
         EncodingResult r{std::vector<int32_t>(text.size() + 1), false};
