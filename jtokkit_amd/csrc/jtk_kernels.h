@@ -158,7 +158,6 @@ void jtk_launch_decode_count(const JtkDecodeWork& w, hipStream_t s);     // mark
 void jtk_launch_decode_scatter(const JtkDecodeWork& w, hipStream_t s);   // scatter, offsets
 
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
-void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);

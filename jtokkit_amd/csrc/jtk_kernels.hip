@@ -2,15 +2,17 @@
 //
 // Stage           kernel            replaces (reference, lib/src/main/java/com/knuddels/jtokkit/)
 // mark_docs       k_mark_docs       document boundaries of the batch (one Encoding.encode call each)
-// special_check   k_special_check   GptBytePairEncoding.java:52-56 (text.contains(specialToken))
-// pretok_split    k_pretok_split    :77-80 matcher.find()/group() with EncodingFactory.java:63,105
-// bpe_merge       k_bpe_merge       :81-86 + bytePairMerge :200-275 + getRank :285-300
-// bpe_merge_long  k_bpe_merge_long  the same for pieces longer than a tile's LDS window
-// pack            k_pack_tokens     out.add / addAll (:82,:117) -- document-order token stream
+// validate_utf8   k_validate_utf8   (optional) String.getBytes(UTF_8) well-formedness per document
+// pretok_split    k_pretok_split    GptBytePairEncoding.java:77-80 matcher.find()/group() with EncodingFactory.java:63,105;
+//                                   for encode(): the special-token check :52-56 (text.contains(specialToken))
+// piece_resolve   k_piece_resolve   :81-83 whole-piece shortcut (TokenEncoder lookups) + queueing of the other pieces
+// bpe_merge       k_bpe_merge_all   :84-86 + bytePairMerge :200-275 + getRank :285-300   (k_bpe_merge_giant: pieces > 8 KiB)
+// pack            k_tile_counts, k_tile_scan, k_pack_tokens, k_doc_offsets   out.add / addAll (:82,:117):
+//                                   the document-order token stream and per-document offsets
 //
-// Integer / byte work only; no floating point, no MFMA.  One lane per byte in pretok_split, one
-// lane per piece in bpe_merge (short pieces) and one wave per piece with a wave-level leftmost-min
-// reduction for long pieces.
+// Integer / byte work only; no floating point, no MFMA.  One lane per 64-byte block in pretok_split, one lane per
+// piece in piece_resolve and bpe_merge (one wave per piece for long pieces, wave-level leftmost-min), one wave per
+// tile in pack.
 #include "jtk_kernels.h"
 
 #include "jtk_merge_core.h"
@@ -79,8 +81,7 @@ __device__ int64_t find_doc(const int64_t* doc_off, int64_t n_docs, int64_t p) {
 
 // ---------------------------------------------------------------------------------------------------
 // special_check: flag documents that contain a special-token literal (all literals start with "<|").
-// The exact test at one position; pretok_split calls it for the '<' bytes it sees (k_special_check is the
-// stand-alone form of the same test).
+// The exact test at one position; pretok_split calls it for the '<' bytes it sees.
 // ---------------------------------------------------------------------------------------------------
 __device__ void special_check_at(const JtkWork& w, const JtkDeviceTables& t, int64_t p) {
     if (p < 0 || p + 1 >= w.n_bytes || w.text[p] != '<' || w.text[p + 1] != '|') return;
@@ -93,32 +94,6 @@ __device__ void special_check_at(const JtkWork& w, const JtkDeviceTables& t, int
         const int64_t d = find_doc(w.doc_off, w.n_docs, p);
         if (d >= 0 && p + len <= w.doc_off[d + 1]) atomicMin(&w.status[d], -2 /* JTK_ERR_UNSUPPORTED_SPECIAL */);
     }
-}
-
-__global__ void __launch_bounds__(256) k_special_check(JtkWork w, JtkDeviceTables t) {
-    const int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (base >= w.n_bytes) return;
-    uint32_t v[4];
-    if (base + 16 <= w.n_bytes) {
-        const uint4 q = *reinterpret_cast<const uint4*>(w.text + base);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
-        for (int i = 0; i < 4; i++) {
-            uint32_t x = 0;
-            for (int j = 0; j < 4; j++) {
-                const int64_t p = base + i * 4 + j;
-                if (p < w.n_bytes) x |= (uint32_t)w.text[p] << (8 * j);
-            }
-            v[i] = x;
-        }
-    }
-    bool any = false;
-    for (int i = 0; i < 4; i++) {
-        const uint32_t x = v[i] ^ 0x3C3C3C3Cu;                       // '<'
-        any |= ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
-    }
-    if (!any) return;
-    for (int k = 0; k < 16; k++) special_check_at(w, t, base + k);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -385,31 +360,6 @@ __global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables
 constexpr int T = JTK_TILE;
 constexpr int TW = T / 64;                                          // mask words per tile
 static_assert(TW <= 64, "tile scans assume at most 64 mask words");
-
-// exclusive scan of cnt[0..n) (n <= 128) into pre[0..n], pre[n] = total; called by one whole wave
-__device__ __forceinline__ void wave_scan_small(const uint32_t* cnt, uint32_t* pre, int n) {
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    for (int c0 = 0; c0 < n; c0 += WAVE) {
-        const uint32_t c = (c0 + lane < n) ? cnt[c0 + lane] : 0u;
-        const uint32_t inc = wave_incl_scan(c);
-        if (c0 + lane < n) pre[c0 + lane] = base + inc - c;
-        base += (uint32_t)__shfl((int)inc, 63);
-    }
-    if (lane == 0) pre[n] = base;
-}
-
-// up to 8 bytes of LDS text starting at (unaligned) offset s, little-endian, zero beyond len
-__device__ __forceinline__ void piece_key(const uint8_t* tx, int s, int len, uint32_t& lo, uint32_t& hi) {
-    const uint32_t* tw = reinterpret_cast<const uint32_t*>(tx);
-    const int a = s >> 2;
-    const uint32_t sh = (uint32_t)(s & 3);
-    const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2];
-    lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-    hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-    if (len < 4) { lo &= (1u << (8 * len)) - 1u; hi = 0; }
-    else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
-}
 
 constexpr int R_OFF0 = 0, R_OFF1 = JTK_RES_CAP0, R_OFF2 = R_OFF1 + JTK_BIN_CAP1, R_OFF3 = R_OFF2 + JTK_BIN_CAP2, R_OFF4 = R_OFF3 + JTK_BIN_CAP3;
 static_assert(R_OFF4 + JTK_BIN_CAP4 == JTK_RES_PER_TILE, "result slots per tile");
@@ -1377,11 +1327,6 @@ __global__ void __launch_bounds__(256) k_doc_offsets(JtkWork w) {
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s) {
     const int64_t n = w.n_docs + 1;
     hipLaunchKernelGGL(k_mark_docs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w);
-}
-void jtk_launch_special_check(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    if (t.n_specials == 0 || w.n_bytes == 0) return;
-    const int64_t threads = (w.n_bytes + 15) / 16;
-    hipLaunchKernelGGL(k_special_check, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w, t);
 }
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s) {
     if (w.n_bytes == 0) return;
