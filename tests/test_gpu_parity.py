@@ -429,3 +429,25 @@ def test_large_batch_1gb(jt):
         doc = text[doc_off[d]:doc_off[d + 1]].tobytes()
         assert res.doc(d).tolist() == o.encode_ordinary(doc), d
     b.close()
+
+
+def test_many_tiny_and_empty_documents(jt):
+    """200k documents of 0..5 bytes (every byte position a document start somewhere, empty documents in runs, multi-byte
+    characters alone in a document): every document equals the oracle, offsets are exact; also through device decode."""
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    rng = random.Random(11)
+    alphabet = ["a", " ", "é", "日", "🍕", "1", "\n", "'s", "<|", "Z", "\r\n", "."]
+    docs = []
+    for _ in range(200000):
+        k = rng.choice((0, 0, 1, 1, 2, 3))
+        docs.append("".join(rng.choice(alphabet) for _ in range(k)).encode("utf-8"))
+    res = enc.encode_batch(docs, ordinary=True)
+    assert (res.status == 0).all()
+    doc_off = np.zeros(len(docs) + 1, dtype=np.int64)
+    np.cumsum([len(d) for d in docs], out=doc_off[1:])
+    text = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    exp_tok, exp_off = o.encode_batch(text, doc_off, threads=8)
+    assert np.array_equal(res.tok_off, exp_off) and np.array_equal(res.tokens, exp_tok)
+    got = enc.decode_batch([res.doc(d).tolist() for d in range(0, 2000)])
+    assert got == docs[:2000]
