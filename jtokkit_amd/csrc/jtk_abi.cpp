@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -297,7 +296,6 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.n_words = (n_bytes + 1 + 63) / 64 + 2;
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
     w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
-    { static const bool pc = []() { const char* e = getenv("JTOKKIT_AMD_MERGE_PC"); return e && e[0] == '1'; }(); w.merge_pc = pc ? 1u : 0u; }
 
     // zeroed per encode: docmask | status | result + list counters | queue counters | chunk sums | tile_extra
     const size_t mask_bytes = (size_t)w.n_words * 8;

@@ -90,7 +90,6 @@ struct JtkWork {
     int64_t n_docs;
     int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
     int64_t n_tiles;
-    uint32_t merge_pc;      // bin 0 of bpe_merge in producer / consumer form (JTOKKIT_AMD_MERGE_PC=1)
     uint32_t check_special; // encode(): flag documents that contain a special-token literal (done inside pretok_split)
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)

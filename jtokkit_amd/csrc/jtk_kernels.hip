@@ -876,267 +876,6 @@ __device__ void merge_piece_wave(uint32_t* ids, uint32_t* rk, int len, const Jtk
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Bin 0 (pieces of 2..16 bytes), producer / consumer form.  The state machine above makes every lane pay for
-// every state's code on every trip, and its divergent steps (expand, emit) run when only some lanes need them.
-// Here the waves of a workgroup specialise:
-//   producer waves  take queue entries 64 at a time, load the text, EXPAND the pieces into free part sets (full
-//                   width), and EMIT finished sets (full width);
-//   consumer waves  only merge: a lane whose piece is finished hands its set back and takes the next ready one.
-// The 1024 part sets ([slot][set]: 16 ids + 15 pair keys; key slot 15 is never used by bytePairMerge -- the last part
-// has no right neighbour -- and carries the set's queue sequence number and length) are split into 64 CLASSES of 16:
-// set = k * 64 + class, and lane l of every wave only ever touches sets of class l, so every LDS access to the parts
-// stays conflict-free (a lane's bank is its lane number, as in the state machine).  Piece number seq belongs to
-// class seq % 64.  Per class, two rings of 16 one-byte entries (k | lap tag << 4) pass sets from the producers to
-// the consumers (ready) and back (done); ring positions are handed out as tickets, nobody scans, every wait is bounded.
-// ---------------------------------------------------------------------------------------------------
-#ifndef JTK_PC_PRODUCERS
-#define JTK_PC_PRODUCERS 5
-#endif
-constexpr int PC_PRODUCERS = JTK_PC_PRODUCERS;  // of the workgroup's 16 waves; the others are consumers
-constexpr int PC_SETS = 1024, PC_CLASS_SETS = 16;
-constexpr uint32_t PC_SPIN_LIMIT = 1u << 22;
-static_assert(16 - PC_PRODUCERS < PC_CLASS_SETS, "some sets of a class must be outside the consumers");
-struct PcLds {
-    volatile uint8_t* ready;      // [64][16]
-    volatile uint8_t* done;       // [64][16]
-    uint32_t* ready_res;          // [64] ready entries written (reserved)
-    uint32_t* ready_head;         // [64] ready tickets handed to consumers
-    uint32_t* done_res;           // [64]
-    uint32_t* misc;               // [0] fresh sets handed out, [1] done rounds handed to producers, [2] abort
-};
-__device__ __forceinline__ uint32_t pc_tag(uint32_t ticket) { return (ticket >> 4) % 15u + 1u; }
-
-__device__ void merge_bin0_pc(const JtkWork& w, const JtkDeviceTables& t, const MergeLds& L, const PcLds& P) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint32_t* const s_id = L.id;
-    uint32_t* const s_rk = L.rk;
-    const int shard = blockIdx.x % JTK_Q_SHARDS;
-    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
-    const uint32_t count = L.count[0];
-    if ((uint64_t)kq * M_CHUNK >= count) return;
-    uint64_t* const queue = w.q[0] + (int64_t)shard * w.q_cap[0];
-    uint32_t n_mine = 0;                                              // entries in this workgroup's chunks
-    for (uint32_t c = kq; (uint64_t)c * M_CHUNK < count; c += K) n_mine += min((uint32_t)M_CHUNK, count - c * M_CHUNK);
-    const uint32_t F = min((uint32_t)PC_SETS, n_mine);                // pieces that start in a fresh set (seq f: set k = f / 64 of class f % 64)
-    const uint32_t n_class = n_mine / 64u + ((uint32_t)lane < n_mine % 64u ? 1u : 0u);   // pieces of my class
-    auto idx_of = [&](uint32_t seq) -> uint32_t { return (kq + (seq / M_CHUNK) * K) * M_CHUNK + (seq % M_CHUNK); };
-    volatile uint32_t* const misc = P.misc;
-    const JtkPairTable pt = t.pairs;
-    uint32_t* const idc = s_id + lane;                                // my class: set k at [slot * 1024 + k * 64]
-    uint32_t* const rkc = s_rk + lane;
-    volatile uint8_t* const ready = P.ready + lane * PC_CLASS_SETS;
-    volatile uint8_t* const done = P.done + lane * PC_CLASS_SETS;
-
-    if (wv < PC_PRODUCERS) {
-        // ------------------------------------------------------------------ producers
-        const JtkBpLds bp{L.bpbits, L.bpcum, L.bpranks};
-        // fill set k of my class with piece number seq (lanes with ok == false idle), then publish it as ready
-        auto fill_and_publish = [&](bool ok, uint32_t k, uint32_t seq, uint64_t entry) {
-            const int64_t pos = (int64_t)(entry & JTK_QE_POS_MASK);
-            const int len = (int)((entry >> JTK_QE_LEN_SHIFT) & 255u) + 1;
-            uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                const int64_t tbase = pos & ~(int64_t)15;
-                const uint4* tx = reinterpret_cast<const uint4*>(w.text + tbase);
-                const uint4 v0 = tx[0], v1 = (tbase + 16 < w.n_bytes) ? tx[1] : tx[0];
-                d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
-            }
-            if (ok) {
-                const uint32_t off = (uint32_t)(pos & 15);
-                const uint32_t q = off >> 2, sh = off & 3u;
-                uint32_t e1[7], e2[5], o[4];
-#pragma unroll
-                for (int i = 0; i < 7; i++) e1[i] = bsel(0u - (q & 1u), d[i + 1], d[i]);
-#pragma unroll
-                for (int i = 0; i < 5; i++) e2[i] = bsel(0u - ((q >> 1) & 1u), e1[i + 2], e1[i]);
-#pragma unroll
-                for (int i = 0; i < 4; i++) o[i] = __builtin_amdgcn_alignbyte(e2[i + 1], e2[i], sh);
-                uint32_t by[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) by[j] = (o[j >> 2] >> (8 * (j & 3))) & 255u;
-                uint32_t* const ids = idc + k * 64;
-                uint32_t* const rks = rkc + k * 64;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    ids[j * PC_SETS] = L.brank[by[j]];
-                    if (j < 15) {
-                        uint32_t r = JTK_RANK_NONE;
-                        if (j + 1 < len) r = jtk_bp_lookup(bp, (by[j] << 8) | by[j + 1]);
-                        rks[j * PC_SETS] = (r == JTK_RANK_NONE) ? RKP_NONE : ((r << 9) | (uint32_t)j);
-                    }
-                }
-                rks[15 * PC_SETS] = seq | ((uint32_t)(len - 1) << 22);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (ok) {
-                const uint32_t r = atomicAdd(&P.ready_res[lane], 1u);
-                ready[r & (PC_CLASS_SETS - 1)] = (uint8_t)(k | (pc_tag(r) << 4));
-            }
-        };
-        // fresh sets: the first F pieces
-        for (;;) {
-            uint32_t f0 = 0;
-            if (lane == 0) f0 = atomicAdd(&P.misc[0], 64u);
-            f0 = (uint32_t)__shfl((int)f0, 0);
-            if (f0 >= F) break;
-            const uint32_t f = f0 + (uint32_t)lane;
-            fill_and_publish(f < F, f0 / 64u, f, f < F ? queue[idx_of(f)] : 0ull);
-        }
-        // finished sets, one per class and round: emit, then refill with the class's next piece
-        for (;;) {
-            uint32_t rd = 0;
-            if (lane == 0) rd = atomicAdd(&P.misc[1], 1u);
-            rd = (uint32_t)__shfl((int)rd, 0);
-            if ((uint64_t)rd * 64u >= n_mine || misc[2]) break;
-            const bool ok = rd < n_class;
-            uint32_t k = 0, spins = 0;
-            for (;;) {                                                   // all 64 of them (full-width emit and expand)
-                const uint32_t e = done[rd & (PC_CLASS_SETS - 1)];
-                const bool got = !ok || (e >> 4) == pc_tag(rd);
-                if (got) k = e & (PC_CLASS_SETS - 1);
-                if (!__ballot(!got)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > PC_SPIN_LIMIT || misc[2]) { if (lane == 0) P.misc[2] = 1u; break; }
-            }
-            if (misc[2]) break;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // the queue entry of the next piece is requested together with the finished piece's (one round trip)
-            const uint32_t seq_new = F + rd * 64u + (uint32_t)lane;
-            const bool refill = ok && seq_new < n_mine;
-            const uint64_t entry_new = refill ? queue[idx_of(seq_new)] : 0ull;
-            // EMIT (:270-273): surviving ids of the set -> the piece's result word / htok, count -> its queue entry
-            if (ok) {
-                const uint32_t* const ids_s = idc + k * 64;
-                const uint32_t meta = rkc[15 * PC_SETS + k * 64];
-                const uint32_t seq = meta & 0x3FFFFFu;
-                const int len = (int)(meta >> 22) + 1;
-                const uint32_t qi = idx_of(seq);
-                const uint64_t entry = queue[qi];
-                const int64_t pos = (int64_t)(entry & JTK_QE_POS_MASK);
-                const uint32_t slot = (uint32_t)(entry >> JTK_QE_IDX_SHIFT) & 1023u;
-                uint32_t ids[16];
-                uint32_t c = 0;
-#pragma unroll
-                for (int j = 0; j < 16; j++) { ids[j] = (j < len) ? ids_s[j * PC_SETS] : JTK_ID_DEAD; c += ids[j] != JTK_ID_DEAD; }
-                const bool slotted = slot < (uint32_t)JTK_RES_CAP0;
-                uint64_t lo = 0, hi = (uint64_t)(c - 1) << 56;
-                if (slotted && c <= 7) {
-                    uint32_t sh = 0;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        if (ids[j] != JTK_ID_DEAD) {
-                            const uint64_t v = ids[j];
-                            if (sh < 64u) lo |= v << sh;
-                            if (sh > 47u) hi |= sh < 64u ? v >> (64u - sh) : v << (sh - 64u);
-                            sh += 17u;
-                        }
-                    }
-                } else {
-                    uint32_t* dst = w.htok + pos;
-                    uint32_t idx = 0;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        if (ids[j] != JTK_ID_DEAD) { dst[idx] = ids[j] | (idx == 0 ? (c << JTK_HT_CNT_SHIFT) : 0u); idx++; }
-                    }
-                }
-                if (slotted)
-                    reinterpret_cast<uint4*>(w.qres)[(pos / T) * JTK_RES_PER_TILE + R_OFF0 + slot] =
-                        make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-                queue[qi] = (uint64_t)(c - 1) << JTK_QE_CNT_SHIFT;
-            }
-            fill_and_publish(refill, k, seq_new, entry_new);
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumers: bytePairMerge :223-268
-    int cur = -1;                         // my part set (k of my class)
-    uint32_t ticket = 0;
-    bool have_ticket = false, finished = false;
-    uint32_t alive = 0, idle_spins = 0;
-    const uint4* const dummy = reinterpret_cast<const uint4*>(pt.buckets);
-    for (;;) {
-        if (cur < 0 && !have_ticket && !finished) {                   // a ticket of my class
-            ticket = atomicAdd(&P.ready_head[lane], 1u);
-            if (ticket >= n_class) finished = true; else have_ticket = true;
-        }
-        if (cur < 0 && have_ticket) {
-            const uint32_t e = ready[ticket & (PC_CLASS_SETS - 1)];
-            if ((e >> 4) == pc_tag(ticket)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                cur = (int)(e & (PC_CLASS_SETS - 1));
-                have_ticket = false;
-                const uint32_t len = (rkc[15 * PC_SETS + cur * 64] >> 22) + 1u;
-                alive = (1u << len) - 1u;                               // len <= 16
-            }
-        }
-        // the merge step of the lanes that have a piece: leftmost minimum of rank << 9 | slot (:234-240)
-        uint32_t* const ids = idc + (cur < 0 ? 0 : cur) * 64;
-        uint32_t* const rks = rkc + (cur < 0 ? 0 : cur) * 64;
-        uint32_t minr = 0, mini = 0, nxt = 0, nn = 0, pv = 0, idnn = 0, idpv = 0;
-        bool has_nn = false, has_pv = false, merging = false, done_now = false;
-        if (cur >= 0) {
-            uint32_t m = RKP_NONE;
-#pragma unroll
-            for (int j = 0; j < 15; j++) m = min(m, rks[j * PC_SETS]);
-            if (m != RKP_NONE) {                                                             // :247
-                merging = true;
-                minr = m >> 9; mini = m & 511u;
-                const uint32_t above = alive & ~((2u << mini) - 1u);                         // live parts after mini
-                nxt = (uint32_t)__builtin_ctz(above);                                        // exists: mini has a right neighbour
-                const uint32_t above2 = above & (above - 1u);
-                has_nn = above2 != 0u;
-                nn = has_nn ? (uint32_t)__builtin_ctz(above2) : 0u;
-                const uint32_t below = alive & ((1u << mini) - 1u);
-                has_pv = below != 0u;
-                pv = has_pv ? 31u - (uint32_t)__builtin_clz(below) : 0u;
-                idnn = ids[nn * PC_SETS];
-                idpv = ids[pv * PC_SETS];
-            } else done_now = true;                                                          // :261
-        }
-        const uint4* a0 = dummy; const uint4* a1 = dummy; const uint4* a2 = dummy; const uint4* a3 = dummy;
-        if (merging) {
-            const uint4* bk = reinterpret_cast<const uint4*>(pt.buckets);
-            if (has_nn) { a0 = bk + jtk_pair_hash(minr, idnn, pt.bits); a1 = bk + jtk_pair_hash2(minr, idnn, pt.bits); }
-            if (has_pv) { a2 = bk + jtk_pair_hash(idpv, minr, pt.bits); a3 = bk + jtk_pair_hash2(idpv, minr, pt.bits); }
-        }
-        const uint64_t b_merge = __ballot(merging);
-        if (b_merge) {
-            const uint4 v0 = *a0, v1 = *a1, v2 = *a2, v3 = *a3;
-            if (merging) {
-                const uint64_t k1 = jtk_pair_key(minr, idnn), k2 = jtk_pair_key(idpv, minr);
-                const JtkPairBucket b11{v0.x, v0.y, v0.z, v0.w}, b12{v1.x, v1.y, v1.z, v1.w};
-                const JtkPairBucket b21{v2.x, v2.y, v2.z, v2.w}, b22{v3.x, v3.y, v3.z, v3.w};
-                uint32_t r1 = JTK_RANK_NONE, r2 = JTK_RANK_NONE;
-                if (has_nn) { const uint32_t x = jtk_pair_match(b11, k1), y = jtk_pair_match(b12, k1); r1 = x != JTK_RANK_NONE ? x : y; }
-                if (has_pv) { const uint32_t x = jtk_pair_match(b21, k2), y = jtk_pair_match(b22, k2); r2 = x != JTK_RANK_NONE ? x : y; }
-                if (has_pv) rks[pv * PC_SETS] = (r2 == JTK_RANK_NONE) ? RKP_NONE : ((r2 << 9) | pv);     // :255-257
-                rks[mini * PC_SETS] = (r1 == JTK_RANK_NONE) ? RKP_NONE : ((r1 << 9) | mini);             // :254
-                if (nxt < 15u) rks[nxt * PC_SETS] = RKP_NONE;
-                ids[mini * PC_SETS] = minr;
-                ids[nxt * PC_SETS] = JTK_ID_DEAD;                                                        // :259
-                alive &= ~(1u << nxt);
-            }
-        }
-        // a finished piece goes back to the producers
-        const uint64_t b_done = __ballot(done_now);
-        if (b_done) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (done_now) {
-                const uint32_t r = atomicAdd(&P.done_res[lane], 1u);
-                done[r & (PC_CLASS_SETS - 1)] = (uint8_t)((uint32_t)cur | (pc_tag(r) << 4));
-                cur = -1;
-            }
-        }
-        if (!__ballot(!finished || cur >= 0 || have_ticket)) break;    // every lane is past the end of its class
-        if (!b_merge && !b_done) {                                     // nothing to do this trip: wait for the producers
-            __builtin_amdgcn_s_sleep(2);
-            if (++idle_spins > PC_SPIN_LIMIT || misc[2]) { if (lane == 0) P.misc[2] = 1u; break; }
-        } else idle_spins = 0;
-    }
-}
-
 // wave `wave_id` of `n_waves` takes every n_waves-th piece of the list; parts in this wave's LDS region (CAP words each)
 template <int CAP>
 __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTables& t, uint32_t* s_id, uint32_t* s_rk,
@@ -1201,13 +940,7 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     __shared__ uint32_t s_brank[256];
     __shared__ uint32_t s_next[JTK_NBINS];
     __shared__ uint32_t s_count[JTK_NBINS + 2];
-    __shared__ uint8_t s_ready[64 * PC_CLASS_SETS], s_done[64 * PC_CLASS_SETS];   // producer / consumer form of bin 0
-    __shared__ uint32_t s_pcc[3 * 64 + 4];
     const int tid = threadIdx.x;
-    if (w.merge_pc) {
-        s_ready[tid] = 0; s_done[tid] = 0;
-        if (tid < 3 * 64 + 4) s_pcc[tid] = 0;
-    }
     for (int i = tid; i < 1024; i += 1024) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += 1024) s_bpranks[i] = t.bp.ranks[i];
     for (int i = tid; i < 256; i += 1024) s_brank[i] = t.byte_rank[i];
@@ -1220,12 +953,7 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     __syncthreads();
     const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
     // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
-    if (w.merge_pc) {
-        const PcLds P{s_ready, s_done, s_pcc, s_pcc + 64, s_pcc + 128, s_pcc + 192};
-        merge_bin0_pc(w, t, L, P);
-        __syncthreads();
-        if (s_pcc[192 + 2] && tid == 0) atomicMin(&w.result->worst_status, -8 /* JTK_ERR_HIP: a bounded wait expired */);
-    } else merge_bin<16, 1024, 0>(w, t, L);
+    merge_bin<16, 1024, 0>(w, t, L);
     if (s_count[1]) { __syncthreads(); merge_bin<32, 512, 1>(w, t, L); }
     if (s_count[2]) { __syncthreads(); merge_bin<64, 256, 2>(w, t, L); }
     if (s_count[3]) { __syncthreads(); merge_bin<128, 128, 3>(w, t, L); }
