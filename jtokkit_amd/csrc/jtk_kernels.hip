@@ -191,7 +191,7 @@ __device__ __forceinline__ uint64_t lo_from_next_lane(uint64_t v) {      // only
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256) k_pretok_split(JtkWork w, JtkDeviceTables t) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_pretok_split(JtkWork w, JtkDeviceTables t) {
     __shared__ uint16_t s_codes[256];          // per-byte flag codes (jtk_byte_code)
     __shared__ uint32_t s_pin[2048];           // byte pairs that occur inside some table entry
     __shared__ uint32_t s_blk[16 * 256 + 4];   // the lanes' blocks, [dword][lane] (staged only for text outside ASCII)
