@@ -366,7 +366,7 @@ static_assert(R_OFF4 + JTK_BIN_CAP4 == JTK_RES_PER_TILE, "result slots per tile"
 constexpr int Q_OFF0 = 0, Q_OFF1 = JTK_BIN_CAP0, Q_OFF2 = Q_OFF1 + JTK_BIN_CAP1, Q_OFF3 = Q_OFF2 + JTK_BIN_CAP2,
               Q_OFF4 = Q_OFF3 + JTK_BIN_CAP3, Q_TOTAL = Q_OFF4 + JTK_BIN_CAP4;
 
-__global__ void __launch_bounds__(256) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
     __shared__ uint16_t s_plist[T + 1];
     __shared__ uint64_t s_pm[TW];
