@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ uint16_t s_plist[T + 1];
     __shared__ uint64_t s_pm[TW];
     __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
-    __shared__ uint32_t s_qn[JTK_NBINS], s_qbase[JTK_NBINS], s_nhard;
+    __shared__ uint32_t s_qn[JTK_NBINS], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -504,26 +504,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         resolve(k0 + 256 + tid, p1);
     }
     __syncthreads();
-    // the tile's slices of its queue shards are claimed with one returning atomic per bin
-    if (tid < JTK_NBINS) {
-        const uint32_t nq = s_qn[tid];
-        const uint32_t qb = nq ? atomicAdd(&w.q_count[tid * JTK_Q_SHARDS + tile % JTK_Q_SHARDS], nq) : 0u;
-        w.q_meta[tile * 16 + tid] = qb;
-        w.q_meta[tile * 16 + 8 + tid] = nq;
-        s_qbase[tid] = qb;
+    // The tile's slices of its queue shards are claimed with one returning atomic per bin (a device-wide atomic:
+    // about 2 us), then the few queue entries are written.  Wave 0 does that alone; the other waves are done and
+    // leave, so their slots go to the next tile's workgroup while the atomic is in flight.
+    if (wv != 0) return;
+    uint32_t nq = 0, qb = 0;
+    if (lane < JTK_NBINS) {
+        nq = s_qn[lane];
+        qb = nq ? atomicAdd(&w.q_count[lane * JTK_Q_SHARDS + tile % JTK_Q_SHARDS], nq) : 0u;
+        w.q_meta[tile * 16 + lane] = qb;
+        w.q_meta[tile * 16 + 8 + lane] = nq;
     }
-    if (tid == 0) {
+    if (lane == 0) {
         w.tile_np[tile] = (uint32_t)np;
         // resolved pieces = one token each; k_tile_counts adds the merged pieces' tokens
         w.tile_cnt[tile] = (uint32_t)np - (s_nhard + s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4]);
     }
-    __syncthreads();
 #pragma unroll
     for (int q = 0; q < JTK_NBINS; q++) {
         const int qoff = q == 0 ? Q_OFF0 : q == 1 ? Q_OFF1 : q == 2 ? Q_OFF2 : q == 3 ? Q_OFF3 : Q_OFF4;
-        uint64_t* dst = w.q[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + s_qbase[q];
-        const uint32_t nq = s_qn[q];
-        for (uint32_t i = tid; i < nq; i += 256) {
+        const uint32_t nq_q = (uint32_t)__shfl((int)nq, q), qb_q = (uint32_t)__shfl((int)qb, q);
+        uint64_t* dst = w.q[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + qb_q;
+        for (uint32_t i = lane; i < nq_q; i += WAVE) {
             const uint32_t e = s_q[qoff + i];
             dst[i] = (uint64_t)(B + (e & 2047u)) | ((uint64_t)(e >> 11) << JTK_QE_LEN_SHIFT);
         }
