@@ -389,8 +389,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     if (tid < TW) {
         const int64_t wd = (B >> 6) + tid;
         uint64_t m = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
-        // the end sentinel (bit n) is not a piece
-        if ((n >> 6) == wd) m &= ~(1ull << (n & 63));
+        // only positions before n start pieces: the end sentinel (bit n) does not, and the padding words after it are
+        // not written by pretok_split for every n (they may hold bits of an earlier, longer batch)
+        if (wd * 64 + 63 >= n) m &= (wd * 64 >= n) ? 0ull : ((1ull << (n - wd * 64)) - 1ull);
         s_pm[tid] = m;
     }
     if (tid < JTK_NBINS) s_qn[tid] = 0;
