@@ -51,9 +51,12 @@ enum { JTK_PATTERN_R50K = 0, JTK_PATTERN_CL100K = 1 };
 enum {
     JTK_ENCODE_ORDINARY = 1u,     /* encodeOrdinary(): skip the special-token check of encode()
                                      (GptBytePairEncoding.java:62-64 vs :47-59) */
-    JTK_ENCODE_VALIDATE_UTF8 = 2u /* also check every document is well-formed UTF-8 (what String.getBytes(UTF_8)
+    JTK_ENCODE_VALIDATE_UTF8 = 2u,/* also check every document is well-formed UTF-8 (what String.getBytes(UTF_8)
                                      produces); offenders get status JTK_ERR_BAD_UTF8.  Without the flag the
                                      input is trusted: malformed bytes are encoded as the bytes they are. */
+    JTK_ENCODE_COUNT_ONLY = 4u    /* Encoding.countTokens() / countTokensOrdinary() (GptBytePairEncoding.java:122-129) for
+                                     the whole batch: token offsets (tok_off[d + 1] - tok_off[d] = the count) and
+                                     status, but no token ids -- fetch with tokens == NULL */
 };
 
 typedef struct jtk_encoding jtk_encoding;

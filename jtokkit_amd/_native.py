@@ -26,6 +26,7 @@ JTK_PATTERN_R50K = 0
 JTK_PATTERN_CL100K = 1
 JTK_ENCODE_ORDINARY = 1
 JTK_ENCODE_VALIDATE_UTF8 = 2
+JTK_ENCODE_COUNT_ONLY = 4
 
 # every symbol include/jtokkit_amd.h declares: (restype, argtypes)
 _p = C.c_void_p

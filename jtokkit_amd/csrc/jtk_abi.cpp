@@ -296,6 +296,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.n_words = (n_bytes + 1 + 63) / 64 + 2;
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
     w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
+    w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
 
     // zeroed per encode: docmask | status | result + list counters | queue counters | chunk sums | tile_extra
     const size_t mask_bytes = (size_t)w.n_words * 8;
@@ -443,6 +444,7 @@ int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* 
     int rc = jtk_batch_result(b, &nt, nullptr, nullptr);
     if (rc != JTK_OK) return rc;
     if (tokens) {
+        if (b->work.count_only) return fail(JTK_ERR_INVALID_ARGUMENT, "the last encode was count-only: there are no token ids");
         if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
         if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->work.tokens, (size_t)nt * 4, hipMemcpyDeviceToHost));
     }
@@ -455,7 +457,7 @@ int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* 
 int jtk_batch_device_result(jtk_batch* b, const int32_t** d_tokens, const int64_t** d_tok_off,
                             const int32_t** d_status) {
     if (!b || !b->have_result) return fail(JTK_ERR_INVALID_ARGUMENT, "no encode has run on this batch");
-    if (d_tokens) *d_tokens = b->work.tokens;
+    if (d_tokens) *d_tokens = b->work.count_only ? nullptr : b->work.tokens;
     if (d_tok_off) *d_tok_off = b->work.tok_off;
     if (d_status) *d_status = b->work.status;
     return JTK_OK;

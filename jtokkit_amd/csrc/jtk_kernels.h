@@ -90,6 +90,7 @@ struct JtkWork {
     int64_t n_docs;
     int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
     int64_t n_tiles;
+    uint32_t count_only;    // countTokens(): pack computes the offsets but writes no token ids
     uint32_t check_special; // encode(): flag documents that contain a special-token literal (done inside pretok_split)
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)

@@ -1214,6 +1214,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     const int np = (int)w.tile_np[tile];
     const uint32_t total = w.tile_tot[tile];
     const bool stage = total <= (uint32_t)PACK_STAGE;
+    const bool store = w.count_only == 0;     // countTokens(): offsets only, no token ids
     const uint32_t* plist = w.plist + B;
     uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens + w.tile_off[tile]);
     uint32_t e[8];
@@ -1235,6 +1236,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     wave_lds_fence();
     uint32_t run = 0;
     // one step: 64 consecutive pieces of the list, entry ej in lane order; out = s_out or dst
+#define STORE(x) do { if (store) { x; } } while (0)
     auto step = [&](uint32_t* out, uint32_t ej, int k) {
         const bool valid = k < np;
         const bool hard = (ej & JTK_PL_HARD) != 0;
@@ -1256,16 +1258,16 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             const uint64_t b0 = __ballot((x & 1u) != 0u), b1 = __ballot((x & 2u) != 0u), b2 = __ballot((x & 4u) != 0u);
             pre = run + (uint32_t)__popcll(bv & lt) + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
             run += (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-            if (valid) out[pre] = (hard ? qe.x : ej) & JTK_HT_ID_MASK;
+            if (valid) STORE(out[pre] = (hard ? qe.x : ej) & JTK_HT_ID_MASK);
             if (b0 | b1 | b2) {
-                if (c > 1u) out[pre + 1] = res_tok<1>(qe);
-                if (c > 2u) out[pre + 2] = res_tok<2>(qe);
+                if (c > 1u) STORE(out[pre + 1] = res_tok<1>(qe));
+                if (c > 2u) STORE(out[pre + 2] = res_tok<2>(qe));
                 if (b1 | b2) {
-                    if (c > 3u) out[pre + 3] = res_tok<3>(qe);
+                    if (c > 3u) STORE(out[pre + 3] = res_tok<3>(qe));
                     if (b2) {
-                        if (c > 4u) out[pre + 4] = res_tok<4>(qe);
-                        if (c > 5u) out[pre + 5] = res_tok<5>(qe);
-                        if (c > 6u) out[pre + 6] = res_tok<6>(qe);
+                        if (c > 4u) STORE(out[pre + 4] = res_tok<4>(qe));
+                        if (c > 5u) STORE(out[pre + 5] = res_tok<5>(qe));
+                        if (c > 6u) STORE(out[pre + 6] = res_tok<6>(qe));
                     }
                 }
             }
@@ -1280,21 +1282,22 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             pre = run + inc - c;
             run += (uint32_t)__shfl((int)inc, 63);
             if (valid) {
-                if (!hard) out[pre] = ej & JTK_HT_ID_MASK;
+                if (!hard) STORE(out[pre] = ej & JTK_HT_ID_MASK);
                 else if (slotted && c <= 7u) {
-                    out[pre] = qe.x & JTK_HT_ID_MASK;
-                    if (c > 1u) out[pre + 1] = res_tok<1>(qe);
-                    if (c > 2u) out[pre + 2] = res_tok<2>(qe);
-                    if (c > 3u) out[pre + 3] = res_tok<3>(qe);
-                    if (c > 4u) out[pre + 4] = res_tok<4>(qe);
-                    if (c > 5u) out[pre + 5] = res_tok<5>(qe);
-                    if (c > 6u) out[pre + 6] = res_tok<6>(qe);
-                } else pack_copy(out + pre, w.htok + B + off, c);
+                    STORE(out[pre] = qe.x & JTK_HT_ID_MASK);
+                    if (c > 1u) STORE(out[pre + 1] = res_tok<1>(qe));
+                    if (c > 2u) STORE(out[pre + 2] = res_tok<2>(qe));
+                    if (c > 3u) STORE(out[pre + 3] = res_tok<3>(qe));
+                    if (c > 4u) STORE(out[pre + 4] = res_tok<4>(qe));
+                    if (c > 5u) STORE(out[pre + 5] = res_tok<5>(qe));
+                    if (c > 6u) STORE(out[pre + 6] = res_tok<6>(qe));
+                } else if (store) pack_copy(out + pre, w.htok + B + off, c);
             }
         }
         // document starts among these pieces: tokens of the tile before them
         if (__ballot(isdoc)) { if (isdoc) w.docpre[B + off] = pre; }
     };
+#undef STORE
     for (int k0 = 0; k0 < np; k0 += 512) {
         if (k0) {
 #pragma unroll
@@ -1307,7 +1310,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             else step(dst, e[j], k0 + j * 64 + lane);
         }
     }
-    if (stage) {
+    if (stage && store) {
         wave_lds_fence();
         for (uint32_t i = lane; i < total; i += WAVE) dst[i] = s_out[i];
     }

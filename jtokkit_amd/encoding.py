@@ -87,11 +87,13 @@ class Batch:
 
     __del__ = close
 
-    def encode_host(self, text_u8, doc_off, ordinary=False, validate=False):
+    def encode_host(self, text_u8, doc_off, ordinary=False, validate=False, count_only=False):
         text_u8 = np.ascontiguousarray(text_u8, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
         nt = C.c_int64(0)
-        flags = (N.JTK_ENCODE_ORDINARY if ordinary else 0) | (N.JTK_ENCODE_VALIDATE_UTF8 if validate else 0)
+        flags = ((N.JTK_ENCODE_ORDINARY if ordinary else 0) | (N.JTK_ENCODE_VALIDATE_UTF8 if validate else 0)
+                 | (N.JTK_ENCODE_COUNT_ONLY if count_only else 0))
+        self._count_only = count_only
         _check(N.lib().jtk_batch_encode(self._h, text_u8.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1,
                                         flags, C.byref(nt)))
         return nt.value
@@ -111,6 +113,14 @@ class Batch:
         nt, nd, ws = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         _check(N.lib().jtk_batch_result(self._h, C.byref(nt), C.byref(nd), C.byref(ws)))
         return nt.value, nd.value, ws.value
+
+    def fetch_counts(self):
+        """Token count per document and status (works after any encode; the only fetch after a count-only one)."""
+        _, nd, _ = self.result()
+        tok_off = np.empty(nd + 1, dtype=np.int64)
+        status = np.zeros(max(nd, 1), dtype=np.int32)
+        _check(N.lib().jtk_batch_fetch(self._h, None, 0, tok_off.ctypes.data, status.ctypes.data))
+        return np.diff(tok_off), status[:nd]
 
     def fetch(self):
         nt, nd, _ = self.result()
@@ -284,6 +294,20 @@ class HipEncoding:
         kept, flag = b.truncate(max_tokens)
         return [EncodingResult(res.tokens[res.tok_off[d]:res.tok_off[d] + kept[d]].tolist(), bool(flag[d]))
                 for d in range(len(bs))]
+
+    def count_tokens_batch(self, texts, ordinary=False):
+        """Encoding.countTokens / countTokensOrdinary for every text, one device call, no token ids written."""
+        bs = [t if isinstance(t, (bytes, bytearray)) else t.encode("utf-8") for t in texts]
+        doc_off = np.zeros(len(bs) + 1, dtype=np.int64)
+        if bs:
+            np.cumsum([len(x) for x in bs], out=doc_off[1:])
+        text = np.frombuffer(b"".join(bs), dtype=np.uint8) if doc_off[-1] else np.zeros(0, dtype=np.uint8)
+        b = self._b()
+        b.encode_host(text, doc_off, ordinary, count_only=True)
+        counts, status = b.fetch_counts()
+        if len(status) and status.min() < 0:
+            _check(int(status.min()))
+        return counts.tolist()
 
     def decode_batch(self, token_lists, strict=True):
         """List of token-id lists -> list of bytes (Encoding.decodeBytes for each), one device call.

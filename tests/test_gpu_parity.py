@@ -472,3 +472,28 @@ def test_batch_reuse_shorter_batch_after_longer(jt):
         # refill the scratch with a longer batch again
         b.encode_host(long_text, np.array([0, len(long_text)], dtype=np.int64), ordinary=True)
     b.close()
+
+
+def test_count_tokens_batch(jt):
+    """JTK_ENCODE_COUNT_ONLY: Encoding.countTokens()/countTokensOrdinary() for a whole batch == len(encode()) of the
+    oracle (GptBytePairEncoding.java:122-129), incl. multi-token pieces, long pieces and empty documents; no ids exist."""
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    rows = golden_util.load_rows("cl100k_base")
+    texts = [r[0] for r in rows] + ["", "a" * 5000, "日本語" * 700, " \n" * 300]
+    assert enc.count_tokens_batch(texts) == [len(o.encode(t)) for t in texts]
+    text, doc_off = corpus.mixed(400, seed=9)
+    b = enc.new_batch()
+    b.encode_host(text, doc_off, ordinary=True, count_only=True)
+    counts, status = b.fetch_counts()
+    exp_tok, exp_off = o.encode_batch(text, doc_off, threads=8)
+    assert (status == 0).all() and np.array_equal(counts, np.diff(exp_off))
+    with pytest.raises(jt.EncodingError):
+        b.fetch()
+    tp, op, sp = b.device_result()
+    assert not tp and op and sp
+    with pytest.raises(jt.UnsupportedOperationError):
+        enc.count_tokens_batch(["a <|endoftext|> b"])
+    assert enc.count_tokens_batch(["a <|endoftext|> b"], ordinary=True) == [len(o.encode_ordinary("a <|endoftext|> b"))]
+    b.close()
