@@ -497,3 +497,29 @@ def test_count_tokens_batch(jt):
         enc.count_tokens_batch(["a <|endoftext|> b"])
     assert enc.count_tokens_batch(["a <|endoftext|> b"], ordinary=True) == [len(o.encode_ordinary("a <|endoftext|> b"))]
     b.close()
+
+
+def test_two_batches_in_flight(jt):
+    """What bench.py does by default: two batch objects of one encoding, each on its own stream, encodes enqueued back to
+    back without waiting (sync=False) on different inputs; both results must be exact.  Repeated so that the two
+    pipelines overlap in different phases."""
+    import torch
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    dev = torch.device("cuda:0")
+    inputs = [corpus.english(3000, seed=71), corpus.mixed(900, seed=72)]
+    expected = [o.encode_batch(t, off, threads=8) for t, off in inputs]
+    d_in = [(torch.from_numpy(t).to(dev), torch.from_numpy(off).to(dev)) for t, off in inputs]
+    torch.cuda.synchronize()
+    batches = [enc.new_batch(), enc.new_batch()]
+    for rep in range(6):
+        order = (0, 1) if rep % 2 == 0 else (1, 0)
+        for i in order:
+            t, off = inputs[i]
+            batches[i].encode_device(d_in[i][0].data_ptr(), d_in[i][1].data_ptr(), len(off) - 1, len(t), ordinary=True, sync=False)
+        for i in (0, 1):
+            res = batches[i].fetch()
+            assert np.array_equal(res.tokens, expected[i][0]) and np.array_equal(res.tok_off, expected[i][1]), (rep, i)
+    for b in batches:
+        b.close()
