@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--ordinary", action="store_true",
                     help="time encodeOrdinary() instead of encode() (skips the special-token check of GptBytePairEncoding.java:52-56)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the after-the-clock check of a document sample against the oracle")
     ap.add_argument("--serial-pass", action="store_true",
                     help="after the timed region, 5 more steps strictly one after the other: per-kernel times without overlap")
     ap.add_argument("--inflight", type=int, default=2,
@@ -231,6 +232,22 @@ def main():
             a = bytes_alg / (serial_ms[dom] * 1e-3) / 1e9
             out["roofline_serial"] = {"kernel": dom_kernel, "achieved": round(a, 2), "frac": round(a / HBM_PEAK_GBS, 5),
                                       "avg_launch_ms": round(serial_ms[dom], 4)}
+        if world == 1 and not args.no_verify:
+            # after the clock (N = 1; with N > 1 the shard's offsets are global): the last result of every batch in flight, a document sample against the CPU oracle
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            o = oracle_lib.get(args.encoding)
+            rng = np.random.default_rng(0)
+            sample = rng.choice(n_docs, min(n_docs, 500), replace=False)
+            for b in batches[:min(n_fl, args.steps + args.warmup)]:
+                res = b.fetch()
+                assert (res.status == 0).all() and int(res.tok_off[-1]) == len(res.tokens) == nt
+                for d in sample:
+                    doc = text[doc_off[d]:doc_off[d + 1]].tobytes()
+                    exp = o.encode(doc) if not args.ordinary else o.encode_ordinary(doc)
+                    if res.doc(int(d)).tolist() != exp:
+                        raise SystemExit("bench: document %d differs from the oracle" % int(d))
+            out["verified"] = "%d sampled documents of each of the %d batches in flight == CPU oracle" % (len(sample), n_fl)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, doc_off, max_threads=args.cpu_threads, ordinary=args.ordinary)
         print(json.dumps(out), flush=True)
