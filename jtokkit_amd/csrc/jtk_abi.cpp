@@ -66,7 +66,7 @@ struct jtk_batch {
     DevBuf in_text, in_off;          // staging for the host-buffer entry point
     DevBuf zeroed;                   // docmask | status | result | list counters | queue counters | pack scan state
     DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, qres, q_meta, mid_list, long_list,
-        giant_list, giant_cnt, giant_off, giant_scratch, tokens, tok_off;
+        giant_list, giant_cnt, tokens, tok_off;
     // batch decode (jtk_batch_decode*)
     DevBuf dec_in_ids, dec_in_off, dec_zero, dec_tile, dec_pre, dec_out, dec_byte_off;
     DevBuf trunc_kept, trunc_flag;   // jtk_batch_truncate
@@ -74,7 +74,6 @@ struct jtk_batch {
     JtkDecodeWork dwork{};
     bool have_decode = false;
     int64_t dec_total = 0;
-    bool giants_pending = false;
     JtkResult* host_result = nullptr;   // pinned
     JtkWork work{};
     bool have_result = false, synced = false;
@@ -85,33 +84,6 @@ struct jtk_batch {
 
 #include "jtk_unicode_tables.h"
 
-
-// Second phase for pieces longer than JTK_LONG_CAP (rare: a run of one byte value, mostly).  The first
-// phase only lists them; once the host has seen the count it sizes the scratch, runs the giant-piece
-// kernel and redoes the pack.  Called after the first phase has been synchronised.
-static int finish_giants(jtk_batch* b) {
-    if (!b->giants_pending) return JTK_OK;
-    b->giants_pending = false;
-    const uint32_t ng = b->host_result->n_giant;
-    if (ng == 0) return JTK_OK;
-    hipStream_t s = b->last_stream;
-    std::vector<JtkLongPiece> list(ng);
-    HIP_TRY(hipMemcpy(list.data(), b->work.giant_list, ng * sizeof(JtkLongPiece), hipMemcpyDeviceToHost));
-    std::vector<int64_t> off(ng + 1, 0);
-    for (uint32_t i = 0; i < ng; i++) off[i + 1] = off[i] + list[i].len;
-    int rc;
-    if ((rc = b->giant_off.ensure((ng + 1) * 8)) || (rc = b->giant_scratch.ensure((size_t)off[ng] * 8 + 64))) return rc;
-    HIP_TRY(hipMemcpyAsync(b->giant_off.p, off.data(), (ng + 1) * 8, hipMemcpyHostToDevice, s));
-    jtk_launch_bpe_merge_giant(b->work, b->enc->dt, ng, (const int64_t*)b->giant_off.p, (uint32_t*)b->giant_scratch.p, s);
-    HIP_TRY(hipMemsetAsync(b->work.chunk_sum, 0, ((size_t)b->work.n_tiles / 4096 + 1) * 8, s));
-    jtk_launch_tile_counts_scan(b->work, s);
-    jtk_launch_pack(b->work, s);
-    jtk_launch_doc_offsets(b->work, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(b->host_result, b->work.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return JTK_OK;
-}
 
 extern "C" {
 
@@ -224,6 +196,7 @@ void jtk_encoding_destroy(jtk_encoding* enc) {
     (void)hipSetDevice(enc->device);
     enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release();
     enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release();
+    enc->dec_off.release(); enc->dec_blob.release();
     delete enc;
 }
 const char* jtk_encoding_name(const jtk_encoding* enc) { return enc ? enc->host.name.c_str() : ""; }
@@ -255,7 +228,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     (void)hipStreamSynchronize(b->stream);
     DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->plist, &b->htok, &b->docpre,
                       &b->tile_np, &b->tile_off, &b->queues, &b->qres, &b->q_meta, &b->giant_cnt, &b->mid_list, &b->long_list,
-                      &b->giant_list, &b->giant_off, &b->giant_scratch, &b->dec_in_ids, &b->dec_in_off, &b->dec_zero,
+                      &b->giant_list, &b->dec_in_ids, &b->dec_in_off, &b->dec_zero,
                       &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag,
                       &b->tokens, &b->tok_off};
     for (DevBuf* d : bufs) d->release();
@@ -394,12 +367,10 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     b->have_trunc = false;
     b->synced = false;
     b->last_stream = s;
-    b->giants_pending = true;
     b->ev_recorded = prof;
     if (n_tokens) {
         HIP_TRY(hipStreamSynchronize(s));
         b->synced = true;
-        if ((rc = finish_giants(b)) != JTK_OK) return rc;
         *n_tokens = b->host_result->n_tokens;
     }
     return JTK_OK;
@@ -432,7 +403,6 @@ int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* 
     if (!b || !b->have_result) return fail(JTK_ERR_INVALID_ARGUMENT, "no encode has run on this batch");
     HIP_TRY(hipSetDevice(b->enc->device));
     if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
-    { const int rcg = finish_giants(b); if (rcg != JTK_OK) return rcg; }
     if (n_tokens) *n_tokens = b->host_result->n_tokens;
     if (n_docs) *n_docs = b->work.n_docs;
     if (worst_status) *worst_status = b->host_result->worst_status;
@@ -484,7 +454,6 @@ int jtk_batch_truncate(jtk_batch* b, int64_t max_tokens) {
     if (!b || !b->have_result || max_tokens < 0) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments (an encode must have run on this batch)");
     HIP_TRY(hipSetDevice(b->enc->device));
     if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
-    { const int rcg = finish_giants(b); if (rcg != JTK_OK) return rcg; }
     const int64_t nd = b->work.n_docs;
     int rc;
     if ((rc = b->trunc_kept.ensure((size_t)(nd > 0 ? nd : 1) * 8)) || (rc = b->trunc_flag.ensure((size_t)(nd > 0 ? nd : 1)))) return rc;

@@ -79,7 +79,7 @@ struct JtkLongPiece {
 struct JtkResult {
     int64_t n_tokens;
     int32_t worst_status;
-    uint32_t n_giant;       // pieces longer than JTK_LONG_CAP, handled in a second phase after a host check
+    uint32_t n_giant;       // pieces longer than JTK_LONG_CAP (listed by piece_resolve, merged by the last phase of k_bpe_merge_all)
 };
 
 // Device-side working set of one encode call (all pointers into the batch's scratch).
@@ -114,8 +114,8 @@ struct JtkWork {
     uint32_t* q_meta;               // [n_tiles][16]: [k] where in its shard the tile's entries of bin k start, [8 + k] how many
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
-    JtkLongPiece* giant_list;// pieces longer than JTK_LONG_CAP (second phase)
-    uint32_t* giant_cnt;    // token count per giant_list entry (0 until the second phase has run)
+    JtkLongPiece* giant_list;// pieces longer than JTK_LONG_CAP
+    uint32_t* giant_cnt;    // token count per giant_list entry
     uint32_t* mid_count;
     uint32_t* long_count;
     int32_t* status;        // per document
@@ -162,9 +162,7 @@ void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
-void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // pieces of up to 8192 bytes
-void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
-                                uint32_t* scratch, hipStream_t s);
+void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_tile_counts_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s);

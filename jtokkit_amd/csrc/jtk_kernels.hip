@@ -6,7 +6,7 @@
 // pretok_split    k_pretok_split    GptBytePairEncoding.java:77-80 matcher.find()/group() with EncodingFactory.java:63,105;
 //                                   for encode(): the special-token check :52-56 (text.contains(specialToken))
 // piece_resolve   k_piece_resolve   :81-83 whole-piece shortcut (TokenEncoder lookups) + queueing of the other pieces
-// bpe_merge       k_bpe_merge_all   :84-86 + bytePairMerge :200-275 + getRank :285-300   (k_bpe_merge_giant: pieces > 8 KiB)
+// bpe_merge       k_bpe_merge_all   :84-86 + bytePairMerge :200-275 + getRank :285-300   (last phase: giant pieces > 8 KiB)
 // pack            k_tile_counts, k_tile_scan, k_pack_tokens, k_doc_offsets   out.add / addAll (:82,:117):
 //                                   the document-order token stream and per-document offsets
 //
@@ -65,7 +65,10 @@ __global__ void __launch_bounds__(256) k_mark_docs(JtkWork w) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > w.n_docs) return;
     const int64_t q = w.doc_off[d];
-    if (q < 0 || q > w.n_bytes) return;
+    // the offsets are caller memory: out-of-range or decreasing ones are reported (JTK_ERR_INVALID_ARGUMENT as the
+    // batch's worst status), never followed
+    const bool bad = q < 0 || q > w.n_bytes || (d > 0 && w.doc_off[d - 1] > q) || (d == 0 && q != 0) || (d == w.n_docs && q != w.n_bytes);
+    if (bad) { atomicMin(&w.result->worst_status, -1 /* JTK_ERR_INVALID_ARGUMENT */); return; }
     atomicOr((unsigned long long*)&w.docmask[q >> 6], 1ull << (q & 63));
 }
 
@@ -486,7 +489,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         else {
             const int64_t len64 = piece_len(k, s);
             if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
-            else w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
+            else if (len64 <= JTK_LONG_CAP) w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
+            else {
+                // giant piece (a run of one byte value, mostly): merged by a whole workgroup in the last phase of
+                // k_bpe_merge_all; its token count goes to giant_cnt, the htok header only says so
+                if (len64 <= JTK_GIANT_CAP) {
+                    const uint32_t gi = atomicAdd(&w.result->n_giant, 1u);
+                    w.giant_list[gi] = JtkLongPiece{B + s, len64};
+                    w.giant_cnt[gi] = 0;
+                } else {
+                    const int64_t d = find_doc(w.doc_off, w.n_docs, B + s);
+                    if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
+                }
+                w.htok[B + s] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;         // count: giant_cnt, or none at all
+            }
             atomicAdd(&s_nhard, 1u);
         }
         if (bin >= 0) {
@@ -600,7 +616,7 @@ struct MergeLds {
     const uint16_t* bpcum;
     const uint32_t* brank;
     uint32_t* next;          // [JTK_NBINS] queue positions handed out, one counter per bin
-    const uint32_t* count;   // [JTK_NBINS + 2] entries in this workgroup's shard of each bin's queue; mid and long list lengths
+    const uint32_t* count;   // [JTK_NBINS + 3] entries in this workgroup's shard of each bin's queue; mid, long and giant list lengths
 };
 
 // One length bin: the first THREADS lanes of the workgroup drain this workgroup's chunks of the bin's queue shard.
@@ -888,20 +904,6 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
     const uint32_t cnt = (CAP == JTK_MID_CAP) ? *w.mid_count : *w.long_count;
     for (uint32_t i = wave_id; i < cnt; i += n_waves) {
         const JtkLongPiece lp = list[i];
-        if (lp.len > CAP) {
-            if (lane == 0) {
-                if (lp.len > JTK_GIANT_CAP) {
-                    const int64_t d = find_doc(w.doc_off, w.n_docs, lp.start);
-                    if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
-                } else {                                                          // second phase (host decides)
-                    const uint32_t gi = atomicAdd(&w.result->n_giant, 1u);
-                    w.giant_list[gi] = lp;
-                    w.giant_cnt[gi] = 0;
-                }
-                w.htok[lp.start] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;  // count: giant_cnt, or none at all
-            }
-            continue;
-        }
         const int len = (int)lp.len;
         for (int j = lane; j < len; j += WAVE) {
             const uint32_t b0 = w.text[lp.start + j];
@@ -929,6 +931,128 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
 }
 
 // ---------------------------------------------------------------------------------------------------
+// merge_giant: pieces of 8 KiB .. 1 MiB (a run of one byte value, mostly).  One workgroup per piece, the last
+// phase of k_bpe_merge_all.  Parts live in the scratch words of the piece's own byte positions -- ids in
+// htok[start ..], pair ranks in docpre[start ..] (pack writes docpre only later) -- so nothing is sized or
+// launched by the host and the whole encode stays asynchronous.  A chunk-minimum cache in LDS (one packed key
+// per 256 positions) keeps a merge at O(#chunks / threads + 256) instead of O(len).  Rare; exact; far cheaper
+// than the reference's O(n^2) list surgery.  key = rank << 20 | position: rank first, leftmost among ties (:236).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+struct GiantLds {
+    uint64_t* cmin;     // [JTK_GIANT_CAP / JTK_GIANT_CHUNK]
+    uint64_t* wmin;     // [16]
+    int* nb;            // [3] nxt, nn, pv
+    uint32_t* r;        // [2]
+};
+
+__device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const GiantLds& L, uint32_t gi) {
+    constexpr int CH = JTK_GIANT_CHUNK;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = blockDim.x, NWV = NT >> 6;
+    const JtkLongPiece lp = w.giant_list[gi];
+    const int len = (int)lp.len;
+    uint32_t* gid = w.htok + lp.start;
+    uint32_t* grk = w.docpre + lp.start;
+    const int nch = (len + CH - 1) / CH;
+    constexpr uint64_t KNONE = ~0ull;
+
+    for (int j = tid; j < len; j += NT) {
+        const uint32_t b0 = w.text[lp.start + j];
+        gid[j] = t.byte_rank[b0];
+        grk[j] = (j + 1 < len) ? t.bp_rank[(b0 << 8) | w.text[lp.start + j + 1]] : JTK_RANK_NONE;
+    }
+    __syncthreads();
+    auto chunk_min = [&](int c) {                 // one wave: minimum key of chunk c
+        uint64_t k = KNONE;
+        for (int q = 0; q < CH / 64; q++) {
+            const int j = c * CH + q * 64 + lane;
+            if (j < len) { const uint32_t r = grk[j]; if (r != JTK_RANK_NONE) { const uint64_t kk = ((uint64_t)r << 20) | (uint32_t)j; k = kk < k ? kk : k; } }
+        }
+        k = wave_min_u64(k);
+        if (lane == 0) L.cmin[c] = k;
+    };
+    for (int c = wv; c < nch; c += NWV) chunk_min(c);
+    __syncthreads();
+
+    for (;;) {
+        uint64_t k = KNONE;
+        for (int c = tid; c < nch; c += NT) { const uint64_t kk = L.cmin[c]; k = kk < k ? kk : k; }
+        k = wave_min_u64(k);
+        if (lane == 0) L.wmin[wv] = k;
+        __syncthreads();
+        k = L.wmin[0];
+        for (int q = 1; q < NWV; q++) k = L.wmin[q] < k ? L.wmin[q] : k;
+        if (k == KNONE) break;                                                               // :247,:261
+        const uint32_t minr = (uint32_t)(k >> 20);
+        const int mini = (int)(k & 0xFFFFFu);
+        // neighbours (parts are at most 128 bytes long): wave 0 finds nxt and nn, wave 1 finds pv
+        if (wv == 0) {
+            int nxt = -1, nn = -1;
+            for (int base = mini + 1; base < len && nn < 0; base += WAVE) {
+                const int j = base + lane;
+                uint64_t bal = __ballot(j < len && gid[j] != JTK_ID_DEAD);
+                if (nxt < 0 && bal) { nxt = base + jtk_ctz64(bal); bal &= bal - 1; }
+                if (nxt >= 0 && bal) nn = base + jtk_ctz64(bal);
+            }
+            if (lane == 0) { L.nb[0] = nxt; L.nb[1] = nn; L.r[0] = nn >= 0 ? jtk_pair_lookup(t.pairs, minr, gid[nn]) : JTK_RANK_NONE; }
+        } else if (wv == 1) {
+            int pv = -1;
+            for (int base = mini - 1; base >= 0 && pv < 0; base -= WAVE) {
+                const int j = base - lane;
+                const uint64_t bal = __ballot(j >= 0 && gid[j] != JTK_ID_DEAD);
+                if (bal) pv = base - jtk_ctz64(bal);
+            }
+            if (lane == 0) { L.nb[2] = pv; L.r[1] = pv >= 0 ? jtk_pair_lookup(t.pairs, gid[pv], minr) : JTK_RANK_NONE; }
+        }
+        __syncthreads();
+        const int nxt = L.nb[0], pv = L.nb[2];
+        if (tid == 0) {
+            gid[mini] = minr; grk[mini] = L.r[0];                                            // :254
+            gid[nxt] = JTK_ID_DEAD; grk[nxt] = JTK_RANK_NONE;                                // :259
+            if (pv >= 0) grk[pv] = L.r[1];                                                   // :255-257
+        }
+        __syncthreads();
+        // refresh the cached minima of the chunks that changed
+        const int c0 = mini / CH, c1 = nxt / CH, c2 = pv >= 0 ? pv / CH : c0;
+        if (wv == 0) chunk_min(c0);
+        if (wv == 1 && c1 != c0) chunk_min(c1);
+        if (wv == 2 && c2 != c0 && c2 != c1) chunk_min(c2);
+        __syncthreads();
+    }
+    // emit (wave 0): surviving ids packed in place from the piece's first position (a survivor never moves up);
+    // count in giant_cnt
+    if (wv == 0) {
+        uint32_t total = 0;
+        uint32_t first = 0;
+        for (int base = 0; base < len; base += WAVE) {
+            const int j = base + lane;
+            const uint32_t v = j < len ? gid[j] : JTK_ID_DEAD;
+            const bool alive = v != JTK_ID_DEAD;
+            const uint64_t bal = __ballot(alive);
+            const uint32_t idx = total + (uint32_t)__popcll(bal & lanemask_lt());
+            if (base == 0) first = (uint32_t)__shfl((int)v, 0);
+            if (alive && idx) gid[idx] = v;
+            total += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) {
+            gid[0] = first | ((uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT);
+            w.giant_cnt[gi] = total;
+            atomicAdd(&w.tile_extra[lp.start / T], total);
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_bpe_merge_all: ONE persistent launch for all of bytePairMerge (except the giant pieces): the five length bins
 // one after the other, then the wave-per-piece lists.  All phases share the 128 KiB of LDS parts and the staged
 // tables; a workgroup barrier separates them (their LDS layouts differ), but there is no device-wide barrier and
@@ -942,7 +1066,7 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     __shared__ uint16_t s_bpcum[1024];
     __shared__ uint32_t s_brank[256];
     __shared__ uint32_t s_next[JTK_NBINS];
-    __shared__ uint32_t s_count[JTK_NBINS + 2];
+    __shared__ uint32_t s_count[JTK_NBINS + 3];
     const int tid = threadIdx.x;
     for (int i = tid; i < 1024; i += 1024) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += 1024) s_bpranks[i] = t.bp.ranks[i];
@@ -953,6 +1077,7 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     }
     if (tid == JTK_NBINS) s_count[JTK_NBINS] = *w.mid_count;
     if (tid == JTK_NBINS + 1) s_count[JTK_NBINS + 1] = *w.long_count;
+    if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = w.result->n_giant;
     __syncthreads();
     const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
     // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
@@ -972,117 +1097,12 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
         __syncthreads();
         if (wv == 0) merge_long<JTK_LONG_CAP>(w, t, s_id, s_rk, blockIdx.x, gridDim.x);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// bpe_merge_giant: pieces of 8 KiB .. 1 MiB (a run of one byte value, mostly).  One workgroup per piece,
-// parts in global scratch (ids[len], rk[len]); a chunk-minimum cache in LDS (one packed key per 256
-// positions) keeps a merge at O(#chunks / 256 + 256) instead of O(len).  Rare; exact; far cheaper than the
-// reference's O(n^2) list surgery.  key = rank << 20 | position: rank first, leftmost among ties (:236).
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
-        const uint64_t o = ((uint64_t)hi << 32) | lo;
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-__global__ void __launch_bounds__(256) k_bpe_merge_giant(JtkWork w, JtkDeviceTables t, const int64_t* scratch_off, uint32_t* scratch) {
-    constexpr int CH = JTK_GIANT_CHUNK;
-    __shared__ uint64_t s_cmin[JTK_GIANT_CAP / CH];
-    __shared__ uint64_t s_wmin[4];
-    __shared__ int s_nb[3];                       // nxt, nn, pv
-    __shared__ uint32_t s_r[2];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const JtkLongPiece lp = w.giant_list[blockIdx.x];
-    const int len = (int)lp.len;
-    uint32_t* gid = scratch + 2 * scratch_off[blockIdx.x];
-    uint32_t* grk = gid + len;
-    const int nch = (len + CH - 1) / CH;
-    constexpr uint64_t KNONE = ~0ull;
-
-    for (int j = tid; j < len; j += 256) {
-        const uint32_t b0 = w.text[lp.start + j];
-        gid[j] = t.byte_rank[b0];
-        grk[j] = (j + 1 < len) ? t.bp_rank[(b0 << 8) | w.text[lp.start + j + 1]] : JTK_RANK_NONE;
-    }
-    __syncthreads();
-    auto chunk_min = [&](int c) {                 // one wave: minimum key of chunk c
-        uint64_t k = KNONE;
-        for (int q = 0; q < CH / 64; q++) {
-            const int j = c * CH + q * 64 + lane;
-            if (j < len) { const uint32_t r = grk[j]; if (r != JTK_RANK_NONE) { const uint64_t kk = ((uint64_t)r << 20) | (uint32_t)j; k = kk < k ? kk : k; } }
-        }
-        k = wave_min_u64(k);
-        if (lane == 0) s_cmin[c] = k;
-    };
-    for (int c = wv; c < nch; c += 4) chunk_min(c);
-    __syncthreads();
-
-    for (;;) {
-        uint64_t k = KNONE;
-        for (int c = tid; c < nch; c += 256) { const uint64_t kk = s_cmin[c]; k = kk < k ? kk : k; }
-        k = wave_min_u64(k);
-        if (lane == 0) s_wmin[wv] = k;
+    // giant pieces (listed by piece_resolve): one workgroup per piece
+    if (s_count[JTK_NBINS + 2]) {
         __syncthreads();
-        k = s_wmin[0];
-        for (int q = 1; q < 4; q++) k = s_wmin[q] < k ? s_wmin[q] : k;
-        if (k == KNONE) break;                                                               // :247,:261
-        const uint32_t minr = (uint32_t)(k >> 20);
-        const int mini = (int)(k & 0xFFFFFu);
-        // neighbours (parts are at most 128 bytes long): wave 0 finds nxt and nn, wave 1 finds pv
-        if (wv == 0) {
-            int nxt = -1, nn = -1;
-            for (int base = mini + 1; base < len && nn < 0; base += WAVE) {
-                const int j = base + lane;
-                uint64_t bal = __ballot(j < len && gid[j] != JTK_ID_DEAD);
-                if (nxt < 0 && bal) { nxt = base + jtk_ctz64(bal); bal &= bal - 1; }
-                if (nxt >= 0 && bal) nn = base + jtk_ctz64(bal);
-            }
-            if (lane == 0) { s_nb[0] = nxt; s_nb[1] = nn; s_r[0] = nn >= 0 ? jtk_pair_lookup(t.pairs, minr, gid[nn]) : JTK_RANK_NONE; }
-        } else if (wv == 1) {
-            int pv = -1;
-            for (int base = mini - 1; base >= 0 && pv < 0; base -= WAVE) {
-                const int j = base - lane;
-                const uint64_t bal = __ballot(j >= 0 && gid[j] != JTK_ID_DEAD);
-                if (bal) pv = base - jtk_ctz64(bal);
-            }
-            if (lane == 0) { s_nb[2] = pv; s_r[1] = pv >= 0 ? jtk_pair_lookup(t.pairs, gid[pv], minr) : JTK_RANK_NONE; }
-        }
-        __syncthreads();
-        const int nxt = s_nb[0], pv = s_nb[2];
-        if (tid == 0) {
-            gid[mini] = minr; grk[mini] = s_r[0];                                            // :254
-            gid[nxt] = JTK_ID_DEAD; grk[nxt] = JTK_RANK_NONE;                                // :259
-            if (pv >= 0) grk[pv] = s_r[1];                                                   // :255-257
-        }
-        __syncthreads();
-        // refresh the cached minima of the chunks that changed
-        const int c0 = mini / CH, c1 = nxt / CH, c2 = pv >= 0 ? pv / CH : c0;
-        if (wv == 0) chunk_min(c0);
-        if (wv == 1 && c1 != c0) chunk_min(c1);
-        if (wv == 2 && c2 != c0 && c2 != c1) chunk_min(c2);
-        __syncthreads();
-    }
-    // emit (wave 0): surviving ids packed from the piece's first position; count in giant_cnt
-    if (wv == 0) {
-        uint32_t total = 0;
-        for (int base = 0; base < len; base += WAVE) {
-            const int j = base + lane;
-            const bool alive = j < len && gid[j] != JTK_ID_DEAD;
-            const uint64_t bal = __ballot(alive);
-            const uint32_t idx = total + (uint32_t)__popcll(bal & lanemask_lt());
-            if (alive && idx) w.htok[lp.start + idx] = gid[j];
-            total += (uint32_t)__popcll(bal);
-        }
-        if (lane == 0) {
-            w.htok[lp.start] = gid[0] | ((uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT);
-            w.giant_cnt[blockIdx.x] = total;
-            atomicAdd(&w.tile_extra[lp.start / T], total);
-        }
+        const GiantLds G{reinterpret_cast<uint64_t*>(s_id), reinterpret_cast<uint64_t*>(s_rk), reinterpret_cast<int*>(s_rk + 64),
+                         s_rk + 72};
+        for (uint32_t gi = blockIdx.x; gi < s_count[JTK_NBINS + 2]; gi += gridDim.x) merge_giant(w, t, G, gi);
     }
 }
 
@@ -1348,10 +1368,6 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_merge_all, dim3(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD), dim3(1024), 0, s, w, t);
-}
-void jtk_launch_bpe_merge_giant(const JtkWork& w, const JtkDeviceTables& t, uint32_t n_giant, const int64_t* scratch_off,
-                                uint32_t* scratch, hipStream_t s) {
-    if (n_giant) hipLaunchKernelGGL(k_bpe_merge_giant, dim3(n_giant), dim3(256), 0, s, w, t, scratch_off, scratch);
 }
 void jtk_launch_tile_counts_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 63) / 64)), dim3(1024), 0, s, w);

@@ -523,3 +523,81 @@ def test_two_batches_in_flight(jt):
             assert np.array_equal(res.tokens, expected[i][0]) and np.array_equal(res.tok_off, expected[i][1]), (rep, i)
     for b in batches:
         b.close()
+
+
+def test_async_encode_with_giant_piece_is_complete(jt):
+    """A non-synchronising device encode (n_tokens == NULL) followed only by a stream sync and reads through
+    jtk_batch_device_result: pieces above 8 KiB (merged by a whole workgroup in the last phase of the merge kernel)
+    must already be in the result -- no host-driven second phase."""
+    import torch
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    docs = [b"before ", b"a" * 10240, b" between", b"=" * 9001 + b" x", b"after"]
+    text = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    doc_off = np.zeros(len(docs) + 1, dtype=np.int64)
+    np.cumsum([len(d) for d in docs], out=doc_off[1:])
+    dev = torch.device("cuda:0")
+    d_text, d_off = torch.from_numpy(text.copy()).to(dev), torch.from_numpy(doc_off).to(dev)
+    torch.cuda.synchronize()
+    b = enc.new_batch()
+    st = torch.cuda.ExternalStream(b.stream(), device=dev)
+    b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(docs), len(text), ordinary=True, sync=False)
+    st.synchronize()
+    tp, op, sp = b.device_result()
+
+    class _Dev:
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+    off = torch.as_tensor(_Dev(op, len(docs) + 1, "<i8"), device=dev).cpu().numpy()
+    status = torch.as_tensor(_Dev(sp, len(docs), "<i4"), device=dev).cpu().numpy()
+    toks = torch.as_tensor(_Dev(tp, int(off[-1]), "<i4"), device=dev).cpu().numpy()
+    assert (status == 0).all()
+    for d, doc in enumerate(docs):
+        assert toks[off[d]:off[d + 1]].tolist() == o.encode_ordinary(doc), d
+    b.close()
+
+
+def test_device_doc_offsets_are_validated(jt):
+    """Offsets handed over in device memory are caller memory: decreasing or out-of-range ones are reported as the
+    batch's worst status (JTK_ERR_INVALID_ARGUMENT), not followed."""
+    import torch
+    enc = jt.get_encoding("cl100k_base")
+    dev = torch.device("cuda:0")
+    text = np.frombuffer(b"hello world, hello again and again", dtype=np.uint8)
+    d_text = torch.from_numpy(text.copy()).to(dev)
+    b = enc.new_batch()
+    for bad in ([0, 20, 10, len(text)], [0, 5, 10**9, len(text)], [0, -3, 9, len(text)], [1, 5, 9, len(text)]):
+        d_off = torch.tensor(bad, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        b.encode_device(d_text.data_ptr(), d_off.data_ptr(), 3, len(text), ordinary=True)
+        assert b.result()[2] == -1, bad
+    d_off = torch.tensor([0, 5, 9, len(text)], dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    b.encode_device(d_text.data_ptr(), d_off.data_ptr(), 3, len(text), ordinary=True)
+    assert b.result()[2] == 0
+    b.close()
+
+
+def test_create_destroy_loop_does_not_leak(jt):
+    """jtk_encoding_create/destroy and jtk_batch_create/destroy give back all device memory (decode tables included)."""
+    import torch
+    from jtokkit_amd import registry
+    enc0 = jt.get_encoding("cl100k_base")          # keeps the HIP context and the cached encoding alive
+    enc0.encode("warm up")
+    torch.cuda.synchronize()
+
+    def one():
+        e = registry.new_encoding("r50k_base", device=0)
+        bt = e.new_batch()
+        bt.encode_host(np.frombuffer(b"some text to encode " * 500, dtype=np.uint8), np.array([0, 10000], dtype=np.int64))
+        assert e.decode_batch([[31373, 995]]) == [b"hello world"]
+        bt.close()
+        e.close()
+    one()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(8):
+        one()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over 8 create/destroy rounds" % (free0 - free1)
