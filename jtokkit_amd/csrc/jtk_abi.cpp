@@ -44,7 +44,7 @@ struct DevBuf {
 
 constexpr int N_STAGES = 8;
 const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "piece_resolve", "bpe_merge",
-                                           "tile_counts_scan", "pack", "doc_offsets"};
+                                           "tile_scan", "pack", "doc_offsets"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -65,7 +65,7 @@ struct jtk_batch {
     hipStream_t last_stream = nullptr;
     DevBuf in_text, in_off;          // staging for the host-buffer entry point
     DevBuf zeroed;                   // docmask | status | result | list counters | queue counters | pack scan state
-    DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, qres, q_meta, mid_list, long_list,
+    DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list,
         giant_list, giant_cnt, tokens, tok_off;
     // batch decode (jtk_batch_decode*)
     DevBuf dec_in_ids, dec_in_off, dec_zero, dec_tile, dec_pre, dec_out, dec_byte_off;
@@ -227,7 +227,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     (void)hipSetDevice(b->enc->device);
     (void)hipStreamSynchronize(b->stream);
     DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->plist, &b->htok, &b->docpre,
-                      &b->tile_np, &b->tile_off, &b->queues, &b->qres, &b->q_meta, &b->giant_cnt, &b->mid_list, &b->long_list,
+                      &b->tile_np, &b->tile_off, &b->queues, &b->q_meta, &b->giant_cnt, &b->mid_list, &b->long_list,
                       &b->giant_list, &b->dec_in_ids, &b->dec_in_off, &b->dec_zero,
                       &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag,
                       &b->tokens, &b->tok_off};
@@ -271,14 +271,12 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
     w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
 
-    // zeroed per encode: docmask | status | result + list counters | queue counters | chunk sums | tile_extra
+    // zeroed per encode: docmask | status | result + list counters | queue counters
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
     const size_t nt = (size_t)w.n_tiles;
     const size_t qcnt_bytes = JTK_NBINS * JTK_Q_SHARDS * 4;
-    const size_t n_chunks = nt / 4096 + 1;
-    const size_t scan_bytes = n_chunks * 8 + nt * 4;
-    const size_t zero_bytes = mask_bytes + status_bytes + 32 + qcnt_bytes + scan_bytes;
+    const size_t zero_bytes = mask_bytes + status_bytes + 32 + qcnt_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
     const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
@@ -286,9 +284,9 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     if ((rc = b->zeroed.ensure(zero_bytes)) || (rc = b->piecemask.ensure(mask_bytes)) ||
         (rc = b->plist.ensure(nt * JTK_TILE * 4)) || (rc = b->htok.ensure(nt * JTK_TILE * 4 + 64)) ||
         (rc = b->docpre.ensure(nt * JTK_TILE * 4)) ||
-        (rc = b->tile_np.ensure(nt * 4 * 3)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
-        (rc = b->q_meta.ensure(nt * 4 * 16)) || (rc = b->qres.ensure(nt * (size_t)JTK_RES_PER_TILE * 16 + 1024)) ||
-        (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 8)) ||
+        (rc = b->tile_np.ensure(align_up(nt * 4, 16) * 2)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
+        (rc = b->q_meta.ensure(nt * 4 * 16)) ||
+        (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 24)) ||
         (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = b->giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
@@ -303,28 +301,28 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     w.mid_count = (uint32_t*)(z + mask_bytes + status_bytes + 16);
     w.long_count = (uint32_t*)(z + mask_bytes + status_bytes + 20);
     w.q_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
-    w.chunk_sum = (uint64_t*)(z + mask_bytes + status_bytes + 32 + qcnt_bytes);
-    w.tile_extra = (uint32_t*)(z + mask_bytes + status_bytes + 32 + qcnt_bytes + n_chunks * 8);
     w.piecemask = (uint64_t*)b->piecemask.p;
     w.plist = (uint32_t*)b->plist.p;
     w.htok = (uint32_t*)b->htok.p;
     w.docpre = (uint32_t*)b->docpre.p;
     w.tile_np = (uint32_t*)b->tile_np.p;
-    w.tile_cnt = w.tile_np + nt;
-    w.tile_tot = w.tile_np + 2 * nt;
+    w.tile_tot = (uint32_t*)((uint8_t*)b->tile_np.p + align_up(nt * 4, 16));
     w.tile_off = (int64_t*)b->tile_off.p;
     {
         const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4};
-        uint64_t* qp = (uint64_t*)b->queues.p;
+        uint8_t* qp = (uint8_t*)b->queues.p;                      // all the 16-byte arrays first, then the 8-byte ones
         w.q_meta = (uint32_t*)b->q_meta.p;
         for (int k = 0; k < JTK_NBINS; k++) {
-            w.q[k] = qp;
+            w.qd[k] = (uint4*)qp;
             w.q_cap[k] = (int64_t)(tps * caps[k]);
-            qp += tps * caps[k] * JTK_Q_SHARDS;
+            qp += tps * caps[k] * JTK_Q_SHARDS * 16;
+        }
+        for (int k = 0; k < JTK_NBINS; k++) {
+            w.qm[k] = (uint64_t*)qp;
+            qp += tps * caps[k] * JTK_Q_SHARDS * 8;
         }
     }
     w.giant_cnt = (uint32_t*)b->giant_cnt.p;
-    w.qres = (uint64_t*)b->qres.p;
     w.mid_list = (JtkLongPiece*)b->mid_list.p;
     w.long_list = (JtkLongPiece*)b->long_list.p;
     w.giant_list = (JtkLongPiece*)b->giant_list.p;
@@ -353,7 +351,7 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     jtk_launch_bpe_merge(w, enc->dt, s);
     end(s);
     begin(s);
-    jtk_launch_tile_counts_scan(w, s);
+    jtk_launch_tile_scan(w, s);
     end(s);
     begin(s);
     jtk_launch_pack(w, s);

@@ -40,14 +40,19 @@ enum { JTK_PAT_R50K = 0, JTK_PAT_CL100K = 1 };
 #define JTK_ID_DEAD 0xFFFFFFFFu            // byte position that does not start a part
 #define JTK_PAIR_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define JTK_PAIR_RANK_MASK 0x3FFFFFFFull
+#define JTK_PAIR_R_MASK 0x1FFFFFFFu         // rank bits of a slot's r word
+#define JTK_PAIR_OVERFLOW 0x20000000u       // in r0: a key whose primary bucket this is lives in its secondary bucket
 
 JTK_HD uint64_t jtk_pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << JTK_ID_BITS) | b; }
 
-// Two-choice bucketed cuckoo table: a key lives in one of two buckets of two 8-byte slots each, so a
-// lookup is exactly two independent 16-byte loads -- never a dependent probe chain.  (On the device a
-// wave advances at the pace of its slowest lane, so "usually one probe, sometimes four" costs four.)
-// The bucket count `nb` is sized for the table to sit in one XCD's 4 MiB L2 with room to spare (any
-// count, not a power of two: bucket = hash32 * nb >> 32).
+// Two-choice bucketed cuckoo tables, PRIMARY FIRST.  What bounds the lookups on the device is the number of
+// scattered cache-line fetches (a CU sustains about one L2 line per 2.3 clocks whatever the width of the load:
+// tools/microbench/gather_rate.hip), so the tables are built for ONE 16-byte load per lookup in the common case:
+// a key lives in its primary bucket unless that was full when the table was built; a bucket that turned a key
+// away carries an OVERFLOW flag.  A lookup reads the primary bucket; a hit, or a miss without the flag, is final
+// -- also for keys that are not in the table, which is most lookups of bytePairMerge.  Only a miss in a flagged
+// bucket reads the secondary one (a second, dependent fetch for those lanes only).
+// Bucket counts are any number, not a power of two: bucket = hash32 * nb >> 32.
 JTK_HD uint32_t jtk_reduce32(uint32_t h, uint32_t nb) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umulhi(h, nb);
@@ -55,56 +60,63 @@ JTK_HD uint32_t jtk_reduce32(uint32_t h, uint32_t nb) {
     return (uint32_t)(((uint64_t)h * nb) >> 32);
 #endif
 }
-JTK_HD uint32_t jtk_pair_hash(uint32_t a, uint32_t b, uint32_t nb) {
+// The two bucket choices share one 32-bit mix of (a, b): the second hash costs one multiply-add, one xor-shift and
+// the reduction on top of the first.
+JTK_HD uint32_t jtk_pair_mix(uint32_t a, uint32_t b) {
     uint32_t h = a * 0x9E3779B1u + b * 0x85EBCA77u;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
     h ^= h >> 16;
-    return jtk_reduce32(h, nb);
+    return h;
 }
-JTK_HD uint32_t jtk_pair_hash2(uint32_t a, uint32_t b, uint32_t nb) {
-    uint32_t h = a * 0xC2B2AE3Du + b * 0x27D4EB2Fu + 0x165667B1u;
-    h ^= h >> 13;
-    h *= 0x9E3779B1u;
-    h ^= h >> 16;
-    return jtk_reduce32(h, nb);
+JTK_HD uint32_t jtk_pair_mix2(uint32_t m) {
+    uint32_t h = m * 0x27D4EB2Fu + 0x165667B1u;
+    h ^= h >> 15;
+    return h;
 }
+JTK_HD uint32_t jtk_pair_hash(uint32_t a, uint32_t b, uint32_t nb) { return jtk_reduce32(jtk_pair_mix(a, b), nb); }
+JTK_HD uint32_t jtk_pair_hash2(uint32_t a, uint32_t b, uint32_t nb) { return jtk_reduce32(jtk_pair_mix2(jtk_pair_mix(a, b)), nb); }
 
-struct JtkPairBucket {          // 16 bytes: two slots
-    uint32_t s0lo, s0hi, s1lo, s1hi;
+// 16 bytes: two slots.  Slot = (k, r): k = low 32 bits of the 34-bit key (id_left << 17 | id_right), r = rank (bits
+// 0..28) | the key's top two bits << 30.  Bit 29 of r0 is the bucket's overflow flag.  An empty slot has k = ~0 and
+// key bits 11 (no id reaches 2^17 - 1).
+struct JtkPairBucket {
+    uint32_t k0, r0, k1, r1;
 };
 struct JtkPairTable {
     const JtkPairBucket* buckets;
     uint32_t bits;   // number of buckets (the field keeps its old name)
 };
 
+// branch-free: the rank stored under (klo, ktop) in this bucket, or JTK_RANK_NONE.  klo = (uint32_t)key,
+// ktop = (uint32_t)(key >> 32) << 30.
+JTK_HD uint32_t jtk_pair_match2(uint32_t k0, uint32_t r0, uint32_t k1, uint32_t r1, uint32_t klo, uint32_t ktop) {
+    const uint32_t d0 = (k0 ^ klo) | ((r0 ^ ktop) & 0xC0000000u);
+    const uint32_t d1 = (k1 ^ klo) | ((r1 ^ ktop) & 0xC0000000u);
+    uint32_t r = JTK_RANK_NONE;
+    r = d1 == 0u ? (r1 & JTK_PAIR_R_MASK) : r;
+    r = d0 == 0u ? (r0 & JTK_PAIR_R_MASK) : r;
+    return r;
+}
 JTK_HD uint32_t jtk_pair_match(const JtkPairBucket& v, uint64_t key) {
-    const uint64_t a = ((uint64_t)v.s0hi << 32) | v.s0lo, b = ((uint64_t)v.s1hi << 32) | v.s1lo;
-    if ((a >> 30) == key) return (uint32_t)(a & JTK_PAIR_RANK_MASK);
-    if ((b >> 30) == key) return (uint32_t)(b & JTK_PAIR_RANK_MASK);
-    return JTK_RANK_NONE;
+    return jtk_pair_match2(v.k0, v.r0, v.k1, v.r1, (uint32_t)key, (uint32_t)(key >> 32) << 30);
 }
 
 JTK_HD uint32_t jtk_pair_lookup(const JtkPairTable& t, uint32_t a, uint32_t b) {
     const uint64_t key = jtk_pair_key(a, b);
-    const JtkPairBucket v1 = t.buckets[jtk_pair_hash(a, b, t.bits)];
-    const JtkPairBucket v2 = t.buckets[jtk_pair_hash2(a, b, t.bits)];
-    const uint32_t r1 = jtk_pair_match(v1, key), r2 = jtk_pair_match(v2, key);
-    return r1 != JTK_RANK_NONE ? r1 : r2;
+    const uint32_t m = jtk_pair_mix(a, b);
+    const JtkPairBucket v1 = t.buckets[jtk_reduce32(m, t.bits)];
+    const uint32_t r1 = jtk_pair_match(v1, key);
+    if (r1 != JTK_RANK_NONE || !(v1.r0 & JTK_PAIR_OVERFLOW)) return r1;
+    const JtkPairBucket v2 = t.buckets[jtk_reduce32(jtk_pair_mix2(m), t.bits)];
+    return jtk_pair_match(v2, key);
 }
 
-// Two lookups, all four loads issued before any is examined.
+// Two lookups (the two neighbours of a merge).
 JTK_HD void jtk_pair_lookup2(const JtkPairTable& t, uint32_t a1, uint32_t b1, bool want1, uint32_t a2, uint32_t b2,
                              bool want2, uint32_t& r1, uint32_t& r2) {
-    const JtkPairBucket none{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    JtkPairBucket v11 = none, v12 = none, v21 = none, v22 = none;
-    if (want1) { v11 = t.buckets[jtk_pair_hash(a1, b1, t.bits)]; v12 = t.buckets[jtk_pair_hash2(a1, b1, t.bits)]; }
-    if (want2) { v21 = t.buckets[jtk_pair_hash(a2, b2, t.bits)]; v22 = t.buckets[jtk_pair_hash2(a2, b2, t.bits)]; }
-    const uint64_t k1 = jtk_pair_key(a1, b1), k2 = jtk_pair_key(a2, b2);
-    const uint32_t x1 = jtk_pair_match(v11, k1), y1 = jtk_pair_match(v12, k1);
-    const uint32_t x2 = jtk_pair_match(v21, k2), y2 = jtk_pair_match(v22, k2);
-    r1 = want1 ? (x1 != JTK_RANK_NONE ? x1 : y1) : JTK_RANK_NONE;
-    r2 = want2 ? (x2 != JTK_RANK_NONE ? x2 : y2) : JTK_RANK_NONE;
+    r1 = want1 ? jtk_pair_lookup(t, a1, b1) : JTK_RANK_NONE;
+    r2 = want2 ? jtk_pair_lookup(t, a2, b2) : JTK_RANK_NONE;
 }
 
 // ---- 2-byte tokens, compressed for LDS: rank of (b0, b1) = ranks[cum[i >> 6] + popcount(bits[i >> 6] below i)]
@@ -129,10 +141,13 @@ JTK_HD uint32_t jtk_bp_lookup(const JtkBpLds& t, uint32_t idx) {
 
 // ---- whole-piece table for pieces of <= 8 bytes -------------------------------------------------------
 // GptBytePairEncoding.java:81-83: a piece that is itself a table entry encodes to that one token.
-// Key = the piece's bytes, little-endian in (lo, hi), zero padded, plus its length.  16-byte slots,
-// two-choice cuckoo (one slot per choice): a lookup is two independent 16-byte loads.
+// Key = the piece's bytes, little-endian in (lo, hi), zero padded, plus its length.  16-byte slots, two-choice
+// cuckoo, one slot per bucket, primary first (see the pair table): one 16-byte load per lookup unless the primary
+// slot carries the overflow flag.
+#define JTK_TOK_OVERFLOW 0x80000000u        // in len: a key whose primary slot this is lives in its secondary slot
+#define JTK_TOK_LEN_MASK 0xFFu
 struct JtkTok8Slot {
-    uint32_t lo, hi, id, len;       // len == 0: empty
+    uint32_t lo, hi, id, len;       // len & JTK_TOK_LEN_MASK == 0: empty
 };
 struct JtkTok8Table {
     const JtkTok8Slot* slots;
@@ -141,34 +156,52 @@ struct JtkTok8Table {
 // ---- whole-piece table for pieces of 9..16 bytes ------------------------------------------------------
 // Same shortcut (GptBytePairEncoding.java:81-83) for the longer words of ordinary text, which would otherwise
 // cost the most merge steps.  Key = 16 bytes little-endian in k[4], zero padded, plus the length.  32-byte slots,
-// two-choice cuckoo, one slot per choice.
+// two-choice cuckoo, one slot per bucket, primary first.
 struct JtkTok16Slot {
     uint32_t k[4];
-    uint32_t id, len, pad0, pad1;   // len == 0: empty
+    uint32_t id, len, pad0, pad1;   // len as in JtkTok8Slot
 };
 struct JtkTok16Table {
     const JtkTok16Slot* slots;
     uint32_t n;
 };
-JTK_HD uint32_t jtk_tok16_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len, uint32_t nslots) {
+// one 32-bit mix of the key for both bucket choices (the second choice re-mixes it: jtk_pair_mix2)
+JTK_HD uint32_t jtk_tok16_mix(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
     uint32_t h = k0 * 0x9E3779B1u + k1 * 0x85EBCA77u + k2 * 0xC2B2AE3Du + (k3 ^ (len << 27)) * 0x27D4EB2Fu;
     h ^= h >> 16;
     h *= 0x2C1B3C6Du;
     h ^= h >> 13;
-    return jtk_reduce32(h, nslots);
+    return h;
+}
+JTK_HD uint32_t jtk_tok16_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len, uint32_t nslots) {
+    return jtk_reduce32(jtk_tok16_mix(k0, k1, k2, k3, len), nslots);
 }
 JTK_HD uint32_t jtk_tok16_hash2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len, uint32_t nslots) {
-    uint32_t h = (k0 ^ (len << 29)) * 0xC2B2AE3Du + k1 * 0x27D4EB2Fu + k2 * 0x9E3779B1u + k3 * 0x165667B1u + 0x85EBCA77u;
-    h ^= h >> 15;
-    h *= 0x85EBCA77u;
-    h ^= h >> 13;
-    return jtk_reduce32(h, nslots);
+    return jtk_reduce32(jtk_pair_mix2(jtk_tok16_mix(k0, k1, k2, k3, len)), nslots);
 }
 
 // the <= 8-byte table hashes the same way (upper key words zero), so the device computes one hash per choice whatever
 // the piece's length
 JTK_HD uint32_t jtk_tok8_hash(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) { return jtk_tok16_hash(lo, hi, 0u, 0u, len, nslots); }
 JTK_HD uint32_t jtk_tok8_hash2(uint32_t lo, uint32_t hi, uint32_t len, uint32_t nslots) { return jtk_tok16_hash2(lo, hi, 0u, 0u, len, nslots); }
+
+// id of the piece (lo, hi, len <= 8) or JTK_RANK_NONE
+JTK_HD uint32_t jtk_tok8_find(const JtkTok8Table& t, uint32_t lo, uint32_t hi, uint32_t len) {
+    const JtkTok8Slot a = t.slots[jtk_tok8_hash(lo, hi, len, t.bits)];
+    if ((a.len & JTK_TOK_LEN_MASK) == len && a.lo == lo && a.hi == hi) return a.id;
+    if (!(a.len & JTK_TOK_OVERFLOW)) return JTK_RANK_NONE;
+    const JtkTok8Slot b = t.slots[jtk_tok8_hash2(lo, hi, len, t.bits)];
+    if ((b.len & JTK_TOK_LEN_MASK) == len && b.lo == lo && b.hi == hi) return b.id;
+    return JTK_RANK_NONE;
+}
+JTK_HD uint32_t jtk_tok16_find(const JtkTok16Table& t, const uint32_t (&k)[4], uint32_t len) {
+    const JtkTok16Slot a = t.slots[jtk_tok16_hash(k[0], k[1], k[2], k[3], len, t.n)];
+    if ((a.len & JTK_TOK_LEN_MASK) == len && a.k[0] == k[0] && a.k[1] == k[1] && a.k[2] == k[2] && a.k[3] == k[3]) return a.id;
+    if (!(a.len & JTK_TOK_OVERFLOW)) return JTK_RANK_NONE;
+    const JtkTok16Slot b = t.slots[jtk_tok16_hash2(k[0], k[1], k[2], k[3], len, t.n)];
+    if ((b.len & JTK_TOK_LEN_MASK) == len && b.k[0] == k[0] && b.k[1] == k[1] && b.k[2] == k[2] && b.k[3] == k[3]) return b.id;
+    return JTK_RANK_NONE;
+}
 
 // ---- Unicode class lookup ----------------------------------------------------------------------------
 struct JtkUcTables {

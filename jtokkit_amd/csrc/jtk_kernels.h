@@ -12,17 +12,15 @@
 #define JTK_TILE 2048            // bytes per piece_resolve / pack workgroup; token counts are kept per tile
 // Pieces that need bytePairMerge are queued by length bin; bin k holds pieces of up to JTK_BIN_SLOTS(k) bytes.
 // Queues are dense and sharded: tile t appends its entries to shard t % JTK_Q_SHARDS with one returning
-// atomic per tile and bin.  Entry: pos (37 bits) | (len - 1) << 37 (8 bits) | index in the tile's list of the bin << 45.
-// After the merge the entry holds (token count - 1) << 56 (summed per tile by k_tile_counts).
-// The merge RESULT of a piece is one 16-byte word in its slot qres[tile][bin offset + index]: (token count - 1) in the
-// top byte | up to seven token ids, 17 bits each from bit 0; a piece that became more than seven tokens, or whose index is
-// beyond the tile's slots of bin 0 (JTK_RES_CAP0), leaves its tokens in htok.
+// atomic per tile and bin.  A queue entry is two words in two parallel arrays:
+//   qm  (8 bytes)   pos (37 bits) | (len - 1) << 37
+//   qd  (16 bytes)  bin 0: IN the piece's bytes (<= 16, what piece_resolve hashed), OUT the merge result;
+//                   bins 1..4: OUT the merge result (their bytes are read from the text)
+// Merge result: (token count - 1) in the top byte | up to seven token ids, 17 bits each from bit 0; a piece that
+// became more than seven tokens leaves its tokens in htok (packed from its first byte position).  The merge kernels
+// add every piece's token count to tile_tot[tile] (piece_resolve stored the resolved pieces' count there).
 #define JTK_QE_POS_MASK ((1ull << 37) - 1ull)
 #define JTK_QE_LEN_SHIFT 37
-#define JTK_QE_IDX_SHIFT 45
-#define JTK_QE_CNT_SHIFT 56
-#define JTK_RES_CAP0 256               // result slots of bin 0 per tile (a tile of ordinary text has a few dozen merged pieces)
-#define JTK_RES_PER_TILE (JTK_RES_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4)
 #define JTK_NBINS 5
 #define JTK_Q_SHARDS 64
 #define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
@@ -101,16 +99,13 @@ struct JtkWork {
                             // piece's first byte position (k <= len words); word 0 also carries the count k: id | k << 17
                             // (JTK_HT_ESCAPE: see giant_cnt)
     uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its tile before it (sparse)
-    uint32_t* tile_cnt;     // [n_tiles] resolved pieces of the tile (one token each)
-    uint32_t* tile_extra;   // [n_tiles] tokens of the tile's pieces merged by the wave / workgroup kernels (zeroed)
-    uint32_t* tile_tot;     // [n_tiles] tokens of the tile's pieces
-    uint64_t* chunk_sum;    // [n_tiles / 4096 + 1] tokens per chunk of 4096 tiles (zeroed per scan)
+    uint32_t* tile_tot;     // [n_tiles] tokens of the tile's pieces: piece_resolve stores the resolved pieces (one token
+                            // each), the merge kernels add theirs
     int64_t* tile_off;      // [n_tiles + 1] exclusive scan of tile_tot
-    uint64_t* q[JTK_NBINS];         // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k
+    uint64_t* qm[JTK_NBINS];        // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k: position and length
+    uint4* qd[JTK_NBINS];           // [JTK_Q_SHARDS][q_cap[k]] ... : bytes in (bin 0), merge result out
     int64_t q_cap[JTK_NBINS];       // entries per shard
     uint32_t* q_count;              // [JTK_NBINS][JTK_Q_SHARDS]
-    uint64_t* qres;                 // [n_tiles][JTK_RES_PER_TILE] x 16 bytes: merge results at fixed slots (only the head of each
-                                    // tile's block is touched)
     uint32_t* q_meta;               // [n_tiles][16]: [k] where in its shard the tile's entries of bin k start, [8 + k] how many
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
@@ -163,7 +158,7 @@ void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
-void jtk_launch_tile_counts_scan(const JtkWork& w, hipStream_t s);
+void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s);
 

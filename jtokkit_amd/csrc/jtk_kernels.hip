@@ -7,13 +7,15 @@
 //                                   for encode(): the special-token check :52-56 (text.contains(specialToken))
 // piece_resolve   k_piece_resolve   :81-83 whole-piece shortcut (TokenEncoder lookups) + queueing of the other pieces
 // bpe_merge       k_bpe_merge_all   :84-86 + bytePairMerge :200-275 + getRank :285-300   (last phase: giant pieces > 8 KiB)
-// pack            k_tile_counts, k_tile_scan, k_pack_tokens, k_doc_offsets   out.add / addAll (:82,:117):
+// pack            k_tile_scan, k_pack_tokens, k_doc_offsets   out.add / addAll (:82,:117):
 //                                   the document-order token stream and per-document offsets
 //
 // Integer / byte work only; no floating point, no MFMA.  One lane per 64-byte block in pretok_split, one lane per
 // piece in piece_resolve and bpe_merge (one wave per piece for long pieces, wave-level leftmost-min), one wave per
 // tile in pack.
 #include "jtk_kernels.h"
+
+#include <type_traits>
 
 #include "jtk_merge_core.h"
 #include "jtk_block_classify.h"
@@ -364,8 +366,6 @@ constexpr int T = JTK_TILE;
 constexpr int TW = T / 64;                                          // mask words per tile
 static_assert(TW <= 64, "tile scans assume at most 64 mask words");
 
-constexpr int R_OFF0 = 0, R_OFF1 = JTK_RES_CAP0, R_OFF2 = R_OFF1 + JTK_BIN_CAP1, R_OFF3 = R_OFF2 + JTK_BIN_CAP2, R_OFF4 = R_OFF3 + JTK_BIN_CAP3;
-static_assert(R_OFF4 + JTK_BIN_CAP4 == JTK_RES_PER_TILE, "result slots per tile");
 constexpr int Q_OFF0 = 0, Q_OFF1 = JTK_BIN_CAP0, Q_OFF2 = Q_OFF1 + JTK_BIN_CAP1, Q_OFF3 = Q_OFF2 + JTK_BIN_CAP2,
               Q_OFF4 = Q_OFF3 + JTK_BIN_CAP3, Q_TOTAL = Q_OFF4 + JTK_BIN_CAP4;
 
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ uint16_t s_plist[T + 1];
     __shared__ uint64_t s_pm[TW];
     __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
-    __shared__ uint32_t s_qn[JTK_NBINS], s_nhard;
+    __shared__ uint32_t s_qn[JTK_NBINS], s_qb[JTK_NBINS], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -424,13 +424,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __syncthreads();
 
     // One lane per piece, two pieces per lane in flight.  A piece of <= 8 bytes looks itself up in the tok8 table, one
-    // of 9..16 bytes in the tok16 table (the reference's whole-piece shortcut, :81-83); either way the lane issues the
-    // same four loads (two slots; key and id/length words), so there is no divergence around the loads.
+    // of 9..16 bytes in the tok16 table (the reference's whole-piece shortcut, :81-83).  The tables are primary-first
+    // (jtk_common.h): ONE scattered fetch per piece (two adjacent words for a 9..16-byte piece) answers hit or miss unless
+    // the slot is flagged "overflowed"; only those lanes read their secondary slot in a second round.
     const int64_t next_after = s_next_after;
-    const JtkTok8Slot* t8 = t.tok8.slots;
-    const JtkTok16Slot* t16 = t.tok16.slots;
+    const uint8_t* const t8 = reinterpret_cast<const uint8_t*>(t.tok8.slots);
+    const uint8_t* const t16 = reinterpret_cast<const uint8_t*>(t.tok16.slots);
     uint32_t* const plist = w.plist + B;
-    struct Probe { int s, len; uint32_t k0, k1, k2, k3; uint4 ka, kb; uint2 ma, mb; };
+    struct Probe { int s, len; uint32_t k0, k1, k2, k3, mix; uint4 ka; uint2 ma; };
     auto piece_len = [&](int k, int s) -> int64_t {
         int64_t e;
         if (k + 1 < np) e = s_plist[k + 1];
@@ -446,6 +447,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             pr.s = s;
             pr.len = len64 > 0x10000 ? 0x10000 : (int)len64;
         }
+        pr.ka = make_uint4(0, 0, 0, 0);
+        pr.ma = make_uint2(0, 0);
         if (pr.s >= 0 && pr.len <= 16) {
             // up to 16 bytes of the piece, zero beyond its length
             const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
@@ -458,29 +461,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
             for (int q = 0; q < 4; q++) k[q] &= (len >= 4u * q + 4u) ? ~0u : (len > 4u * q ? part : 0u);
             pr.k0 = k[0]; pr.k1 = k[1]; pr.k2 = k[2]; pr.k3 = k[3];
-            // one hash per choice for both tables; only base, slot size and slot count depend on the length
+            // one mix for both tables and both choices; only base, slot size and slot count depend on the length
+            pr.mix = jtk_tok16_mix(k[0], k[1], k[2], k[3], len);
             const bool small = len <= 8u;
-            const uint32_t nsl = small ? t.tok8.bits : t.tok16.n;
-            const uint8_t* base = small ? reinterpret_cast<const uint8_t*>(t8) : reinterpret_cast<const uint8_t*>(t16);
-            const uint32_t shift = small ? 4u : 5u, moff = small ? 8u : 16u;          // slot bytes, offset of (id, len)
-            const uint8_t* sa = base + ((uint64_t)jtk_tok16_hash(k[0], k[1], k[2], k[3], len, nsl) << shift);
-            const uint8_t* sb = base + ((uint64_t)jtk_tok16_hash2(k[0], k[1], k[2], k[3], len, nsl) << shift);
-            const uint4 *pa = reinterpret_cast<const uint4*>(sa), *pb = reinterpret_cast<const uint4*>(sb);
-            const uint2 *qa = reinterpret_cast<const uint2*>(sa + moff), *qb = reinterpret_cast<const uint2*>(sb + moff);
-            pr.ka = *pa; pr.kb = *pb; pr.ma = *qa; pr.mb = *qb;
+            const uint8_t* sa = (small ? t8 : t16) + ((size_t)jtk_reduce32(pr.mix, small ? t.tok8.bits : t.tok16.n) << (small ? 4 : 5));
+            pr.ka = *reinterpret_cast<const uint4*>(sa);                 // tok8: lo, hi, id, len; tok16: the 16 key bytes
+            if (!small) pr.ma = *reinterpret_cast<const uint2*>(sa + 16);   // tok16: id, len
         }
     };
-    auto resolve = [&](int k, const Probe& pr) {
+    // the answer of a slot: id, or JTK_RANK_NONE; `more`: a miss that the secondary slot has to confirm
+    auto check = [&](const Probe& pr, uint32_t& id, bool& more) {
+        const uint32_t len = (uint32_t)pr.len;
+        const bool small = len <= 8u;
+        const uint32_t slen = small ? pr.ka.w : pr.ma.y;
+        const bool hit = (slen & JTK_TOK_LEN_MASK) == len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1 &&
+                         (small || (pr.ka.z == pr.k2 && pr.ka.w == pr.k3));
+        id = hit ? (small ? pr.ka.z : pr.ma.x) : JTK_RANK_NONE;
+        more = !hit && (slen & JTK_TOK_OVERFLOW) != 0u;
+    };
+    auto issue2 = [&](Probe& pr) {                                       // secondary slot
+        const bool small = pr.len <= 8;
+        const uint8_t* sa = (small ? t8 : t16) + ((size_t)jtk_reduce32(jtk_pair_mix2(pr.mix), small ? t.tok8.bits : t.tok16.n) << (small ? 4 : 5));
+        pr.ka = *reinterpret_cast<const uint4*>(sa);
+        if (!small) pr.ma = *reinterpret_cast<const uint2*>(sa + 16);
+    };
+    auto resolve = [&](int k, const Probe& pr, uint32_t id) {
         if (pr.s < 0) return;
         const int s = pr.s, len = pr.len;
         uint32_t entry = JTK_PL_HARD | JTK_PL_NOQUEUE | (uint32_t)s;
         int bin = -1;
         if (len <= 16) {
-            uint32_t id = JTK_RANK_NONE;
-            const bool small = len <= 8;                              // tok8 slots hold (lo, hi, id, len): compare two key words
-            const bool hit_a = pr.ma.y == (uint32_t)len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1 && (small || (pr.ka.z == pr.k2 && pr.ka.w == pr.k3));
-            const bool hit_b = pr.mb.y == (uint32_t)len && pr.kb.x == pr.k0 && pr.kb.y == pr.k1 && (small || (pr.kb.z == pr.k2 && pr.kb.w == pr.k3));
-            if (hit_a) id = pr.ma.x; else if (hit_b) id = pr.mb.x;
             if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT); else bin = 0;
         } else if (len <= 32) bin = 1;
         else if (len <= 64) bin = 2;
@@ -517,36 +527,335 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         Probe p0, p1;
         issue(k0 + tid, p0);
         issue(k0 + 256 + tid, p1);
-        resolve(k0 + tid, p0);
-        resolve(k0 + 256 + tid, p1);
+        uint32_t id0, id1;
+        bool more0, more1;
+        check(p0, id0, more0);
+        check(p1, id1, more1);
+        more0 = more0 && p0.s >= 0 && p0.len <= 16;
+        more1 = more1 && p1.s >= 0 && p1.len <= 16;
+        if (__ballot(more0 || more1)) {
+            if (more0) issue2(p0);
+            if (more1) issue2(p1);
+            bool dummy;
+            if (more0) check(p0, id0, dummy);
+            if (more1) check(p1, id1, dummy);
+        }
+        resolve(k0 + tid, p0, id0);
+        resolve(k0 + 256 + tid, p1, id1);
     }
     __syncthreads();
     // The tile's slices of its queue shards are claimed with one returning atomic per bin (a device-wide atomic:
-    // about 2 us), then the few queue entries are written.  Wave 0 does that alone; the other waves are done and
-    // leave, so their slots go to the next tile's workgroup while the atomic is in flight.
-    if (wv != 0) return;
-    uint32_t nq = 0, qb = 0;
-    if (lane < JTK_NBINS) {
-        nq = s_qn[lane];
-        qb = nq ? atomicAdd(&w.q_count[lane * JTK_Q_SHARDS + tile % JTK_Q_SHARDS], nq) : 0u;
-        w.q_meta[tile * 16 + lane] = qb;
-        w.q_meta[tile * 16 + 8 + lane] = nq;
-    }
-    if (lane == 0) {
-        w.tile_np[tile] = (uint32_t)np;
-        // resolved pieces = one token each; k_tile_counts adds the merged pieces' tokens
-        w.tile_cnt[tile] = (uint32_t)np - (s_nhard + s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4]);
-    }
-#pragma unroll
-    for (int q = 0; q < JTK_NBINS; q++) {
-        const int qoff = q == 0 ? Q_OFF0 : q == 1 ? Q_OFF1 : q == 2 ? Q_OFF2 : q == 3 ? Q_OFF3 : Q_OFF4;
-        const uint32_t nq_q = (uint32_t)__shfl((int)nq, q), qb_q = (uint32_t)__shfl((int)qb, q);
-        uint64_t* dst = w.q[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + qb_q;
-        for (uint32_t i = lane; i < nq_q; i += WAVE) {
-            const uint32_t e = s_q[qoff + i];
-            dst[i] = (uint64_t)(B + (e & 2047u)) | ((uint64_t)(e >> 11) << JTK_QE_LEN_SHIFT);
+    // about 2 us), then the queue entries are written: position and length for every bin, and for bin 0 also the
+    // piece's bytes (so that the merge kernel reads 16 dense bytes per piece instead of a 64-byte slab of the text).
+    // A tile with few merge pieces (ordinary text) leaves that to wave 0; the other waves are done and leave, so
+    // their slots go to the next tile's workgroup while the atomic is in flight.
+    const uint32_t n_queued = s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4];
+    const bool all_waves = n_queued > 64u;                           // workgroup-uniform
+    if (!all_waves && wv != 0) return;
+    if (wv == 0) {
+        uint32_t nq = 0, qb = 0;
+        if (lane < JTK_NBINS) {
+            nq = s_qn[lane];
+            qb = nq ? atomicAdd(&w.q_count[lane * JTK_Q_SHARDS + tile % JTK_Q_SHARDS], nq) : 0u;
+            w.q_meta[tile * 16 + lane] = qb;
+            w.q_meta[tile * 16 + 8 + lane] = nq;
+            s_qb[lane] = qb;
+        }
+        if (lane == 0) {
+            w.tile_np[tile] = (uint32_t)np;
+            // resolved pieces = one token each; the merge kernels add the merged pieces' tokens
+            w.tile_tot[tile] = (uint32_t)np - (s_nhard + n_queued);
         }
     }
+    if (all_waves) __syncthreads(); else wave_lds_fence();
+    const int nthr = all_waves ? 256 : WAVE, me = all_waves ? tid : lane;
+    {   // bin 0: bytes + meta
+        const uint32_t nq0 = s_qn[0];
+        const int64_t qbase = (tile % JTK_Q_SHARDS) * w.q_cap[0] + s_qb[0];
+        const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
+        for (uint32_t i = (uint32_t)me; i < nq0; i += (uint32_t)nthr) {
+            const uint32_t e = s_q[Q_OFF0 + i];
+            const uint32_t off = e & 2047u;
+            const int a = (int)(off >> 2);
+            const uint32_t sh = off & 3u;
+            const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2], w3 = tw[a + 3], w4 = tw[a + 4];
+            w.qd[0][qbase + i] = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                            __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+            w.qm[0][qbase + i] = (uint64_t)(B + off) | ((uint64_t)((e >> 11) & 255u) << JTK_QE_LEN_SHIFT);
+        }
+    }
+#pragma unroll
+    for (int q = 1; q < JTK_NBINS; q++) {
+        const int qoff = q == 1 ? Q_OFF1 : q == 2 ? Q_OFF2 : q == 3 ? Q_OFF3 : Q_OFF4;
+        const uint32_t nq_q = s_qn[q];
+        uint64_t* dst = w.qm[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + s_qb[q];
+        for (uint32_t i = (uint32_t)me; i < nq_q; i += (uint32_t)nthr) {
+            const uint32_t e = s_q[qoff + i];
+            dst[i] = (uint64_t)(B + (e & 2047u)) | ((uint64_t)((e >> 11) & 255u) << JTK_QE_LEN_SHIFT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_bpe_merge_lean: bytePairMerge (GptBytePairEncoding.java:200-275) of the queued pieces of <= 64 bytes -- all
+// but a handful of the pieces that need merging -- ONE LANE PER PIECE, no state machine: a wave takes 64 consecutive
+// queue entries, expands them (byte -> id and the 2-byte-token ranks from LDS tables), then all lanes step together:
+// leftmost minimum over the pair keys (:234-240), the two neighbour lookups in the (left id, right id) pair table,
+// update (:248-259); a lane whose piece is finished idles until the wave's last piece is.  Entries of one wave come
+// from the same stretch of text, so their lengths are alike; the slots scanned per step are bounded by the wave's
+// longest piece (NS: a compile-time unrolled scan, all LDS reads of a step in flight together).
+// What bounds the kernel is the number of scattered cache-line fetches (tools/microbench/gather_rate.hip: a CU
+// sustains one per ~2.3 clocks), so a step fetches as few as it can: the pair table is primary-first (jtk_common.h) --
+// ONE 16-byte load per lookup, issued for both lookups together; only lanes that miss in a bucket flagged "overflowed"
+// read their secondary bucket -- and a lookup whose two parts make up the whole piece is not made at all: the piece
+// is not a table entry, or piece_resolve would not have queued it (bin 0).
+// Parts live in LDS laid out [slot][lane] (conflict-free for any per-lane slot); key = rank << 6 | slot orders by rank
+// first and leftmost among equal ranks (:236).
+// Bin 0 (<= 16 bytes): the piece's bytes are in the queue entry (written by piece_resolve); the result replaces them.
+// Bins 1, 2 (<= 32, <= 64 bytes; rare): bytes from the text.  Token counts are summed per tile into tile_tot.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t KL_NONE = 0xFFFFFFFFu;
+constexpr int ML_THREADS = 1024;
+constexpr int ML_WGS_PER_SHARD = 4;
+
+struct LeanLds {
+    uint32_t* id;            // [16384] parts: token ids, [slot][lane]
+    uint32_t* rk;            // [16384] parts: pair keys
+    JtkBpLds bp;             // 2-byte tokens
+    const uint32_t* brank;   // [256]
+};
+
+// merge steps on the first NS slots; returns the live-part mask.  SKIP_WHOLE: the piece itself is known not to be a
+// table entry.
+template <int NS, int STRIDE, bool SKIP_WHOLE, class M>
+__device__ __forceinline__ M lean_steps(uint32_t* id, uint32_t* rk, M alive, const uint8_t* bk, uint32_t nb) {
+    for (;;) {
+        uint32_t k[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) k[j] = rk[j * STRIDE];
+#pragma unroll
+        for (int d = 1; d < NS; d <<= 1) {
+#pragma unroll
+            for (int j = 0; j + d < NS; j += 2 * d) k[j] = min(k[j], k[j + d]);
+        }
+        const uint32_t m = k[0];
+        const bool act = m != KL_NONE;                                                       // :247,:261
+        if (!__ballot(act)) break;
+        const uint32_t minr = act ? (m >> 6) : 0u, mini = act ? (m & 63u) : 0u;
+        const M one = 1;
+        const M above = alive & ~(((one << mini) << 1) - one);
+        const M above2 = above & (above - one);
+        const M below = alive & ((one << mini) - one);
+        const bool has_nn = act && above2 != 0, has_pv = act && below != 0;
+        uint32_t nxt, nn, pv;
+        if (sizeof(M) == 8) {
+            nxt = above ? (uint32_t)jtk_ctz64(above) : 0u;
+            nn = above2 ? (uint32_t)jtk_ctz64(above2) : 0u;
+            pv = below ? 63u - (uint32_t)jtk_clz64(below) : mini;
+        } else {
+            nxt = above ? (uint32_t)__builtin_ctz((uint32_t)above) : 0u;
+            nn = above2 ? (uint32_t)__builtin_ctz((uint32_t)above2) : 0u;
+            pv = below ? 31u - (uint32_t)__builtin_clz((uint32_t)below) : mini;
+        }
+        // (minr, id of the part after next) and (id of the previous part, minr); a pair that would be the whole piece is
+        // known to be absent
+        bool want1 = has_nn, want2 = has_pv;
+        if (SKIP_WHOLE) {
+            want1 = want1 && !(mini == 0u && (above2 & (above2 - one)) == 0);
+            want2 = want2 && !(pv == 0u && !has_nn);
+        }
+        const uint32_t idnn = want1 ? id[nn * STRIDE] : 0u, idpv = want2 ? id[pv * STRIDE] : 0u;
+        const uint32_t a1 = want1 ? minr : 0u, b2 = want2 ? minr : 0u;
+        const uint32_t m1 = jtk_pair_mix(a1, idnn), m2 = jtk_pair_mix(idpv, b2);
+        const uint4 v0 = *reinterpret_cast<const uint4*>(bk + ((size_t)jtk_reduce32(m1, nb) << 4));
+        const uint4 v2 = *reinterpret_cast<const uint4*>(bk + ((size_t)jtk_reduce32(m2, nb) << 4));
+        const uint32_t klo1 = (a1 << JTK_ID_BITS) | idnn, kt1 = (a1 >> (32 - JTK_ID_BITS)) << 30;
+        const uint32_t klo2 = (idpv << JTK_ID_BITS) | b2, kt2 = (idpv >> (32 - JTK_ID_BITS)) << 30;
+        uint32_t r1 = jtk_pair_match2(v0.x, v0.y, v0.z, v0.w, klo1, kt1);
+        uint32_t r2 = jtk_pair_match2(v2.x, v2.y, v2.z, v2.w, klo2, kt2);
+        const bool more1 = want1 && r1 == JTK_RANK_NONE && (v0.y & JTK_PAIR_OVERFLOW) != 0u;
+        const bool more2 = want2 && r2 == JTK_RANK_NONE && (v2.y & JTK_PAIR_OVERFLOW) != 0u;
+        if (__ballot(more1 || more2)) {
+            // the secondary buckets, for the lanes that need them (the others re-read bucket lines they just had)
+            const uint32_t h1 = more1 ? jtk_reduce32(jtk_pair_mix2(m1), nb) : jtk_reduce32(m1, nb);
+            const uint32_t h2 = more2 ? jtk_reduce32(jtk_pair_mix2(m2), nb) : jtk_reduce32(m2, nb);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(bk + ((size_t)h1 << 4));
+            const uint4 v3 = *reinterpret_cast<const uint4*>(bk + ((size_t)h2 << 4));
+            const uint32_t y1 = jtk_pair_match2(v1.x, v1.y, v1.z, v1.w, klo1, kt1), y2 = jtk_pair_match2(v3.x, v3.y, v3.z, v3.w, klo2, kt2);
+            r1 = more1 ? y1 : r1;
+            r2 = more2 ? y2 : r2;
+        }
+        r1 = want1 ? r1 : JTK_RANK_NONE;
+        r2 = want2 ? r2 : JTK_RANK_NONE;
+        if (act) {
+            // without a previous part the first store lands on slot mini and is overwritten by the second
+            rk[pv * STRIDE] = (r2 == JTK_RANK_NONE) ? KL_NONE : ((r2 << 6) | pv);                           // :255-257
+            rk[mini * STRIDE] = (r1 == JTK_RANK_NONE) ? KL_NONE : ((r1 << 6) | mini);                       // :254
+            rk[nxt * STRIDE] = KL_NONE;
+            id[mini * STRIDE] = minr;
+            alive &= ~(one << nxt);                                                                          // :259
+        }
+    }
+    return alive;
+}
+
+// expand (:206-221) + merge for pieces whose bytes are in registers: b[j] = byte j of the lane's piece (0 beyond its end)
+template <int NS, int STRIDE>
+__device__ __forceinline__ uint32_t lean_piece16(const LeanLds& L, uint32_t* id, uint32_t* rk, const uint32_t (&b)[NS + 1], int len,
+                                                 const JtkDeviceTables& t) {
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const uint32_t r = (j + 1 < len) ? jtk_bp_lookup(L.bp, (b[j] << 8) | b[j + 1]) : JTK_RANK_NONE;
+        id[j * STRIDE] = L.brank[b[j]];
+        rk[j * STRIDE] = (r != JTK_RANK_NONE) ? ((r << 6) | (uint32_t)j) : KL_NONE;
+    }
+    const uint32_t alive0 = (1u << len) - 1u;
+    return lean_steps<NS, STRIDE, true, uint32_t>(id, rk, alive0, reinterpret_cast<const uint8_t*>(t.pairs.buckets), t.pairs.bits);
+}
+
+template <int SLOTS, int THREADS, int BIN>
+__device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables& t, const LeanLds& L, uint32_t count) {
+    typedef typename std::conditional<(SLOTS > 32), uint64_t, uint32_t>::type M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid >= THREADS) return;
+    const int shard = blockIdx.x % JTK_Q_SHARDS;
+    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
+    uint32_t* const id = L.id + tid;
+    uint32_t* const rk = L.rk + tid;
+    const uint64_t* const qm = w.qm[BIN] + (int64_t)shard * w.q_cap[BIN];
+    uint4* const qd = w.qd[BIN] + (int64_t)shard * w.q_cap[BIN];
+
+    for (uint32_t base = kq * THREADS; base < count; base += K * THREADS) {
+        const uint32_t qi = base + (uint32_t)tid;
+        const bool have = qi < count;
+        uint64_t meta = 0;
+        uint4 by = make_uint4(0, 0, 0, 0);
+        if (have) { meta = qm[qi]; if (BIN == 0) by = qd[qi]; }
+        const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
+        const int len = have ? (int)((meta >> JTK_QE_LEN_SHIFT) & 255u) + 1 : 0;
+        M alive;
+        if (BIN == 0) {
+            const uint32_t d4[4] = {by.x, by.y, by.z, by.w};
+            uint32_t b[17];
+#pragma unroll
+            for (int j = 0; j < 16; j++) b[j] = (d4[j >> 2] >> (8 * (j & 3))) & 255u;
+            b[16] = 0;
+            // the wave's longest piece picks the unrolled variant (wave-uniform)
+            if (!__ballot(len > 8)) {
+                if (!__ballot(len > 4)) { uint32_t c[5]; for (int j = 0; j < 5; j++) c[j] = b[j]; alive = lean_piece16<4, THREADS>(L, id, rk, c, len, t); }
+                else { uint32_t c[9]; for (int j = 0; j < 9; j++) c[j] = b[j]; alive = lean_piece16<8, THREADS>(L, id, rk, c, len, t); }
+            } else {
+                if (!__ballot(len > 12)) { uint32_t c[13]; for (int j = 0; j < 13; j++) c[j] = b[j]; alive = lean_piece16<12, THREADS>(L, id, rk, c, len, t); }
+                else alive = lean_piece16<16, THREADS>(L, id, rk, b, len, t);
+            }
+        } else {
+            // the piece's bytes from the text: the aligned 16-byte words that cover it are parked in the (idle) key slots,
+            // then expanded in two passes (byte pairs into the id slots; ids and keys from those)
+            const int64_t tb = pos & ~(int64_t)15;
+            const uint32_t off = (uint32_t)(pos & 15);
+            constexpr int NQ = SLOTS / 16 + 1;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (have && tb + 16 * q < w.n_bytes && (int)(16 * q) < (int)off + len) v = *reinterpret_cast<const uint4*>(w.text + tb + 16 * q);
+                rk[(4 * q + 0) * THREADS] = v.x; rk[(4 * q + 1) * THREADS] = v.y; rk[(4 * q + 2) * THREADS] = v.z; rk[(4 * q + 3) * THREADS] = v.w;
+            }
+            int maxlen = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d));
+            maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+            const uint8_t* rkb = reinterpret_cast<const uint8_t*>(rk);
+            uint32_t prev = rkb[(off >> 2) * THREADS * 4 + (off & 3)];
+            for (int j = 0; j < maxlen; j++) {
+                const uint32_t o = off + j + 1;
+                const uint32_t cur = rkb[(o >> 2) * THREADS * 4 + (o & 3)];
+                id[j * THREADS] = (prev << 8) | cur;                  // byte pair, expanded below
+                prev = cur;
+            }
+            for (int j = 0; j < SLOTS; j++) {
+                if (j < maxlen) {
+                    const uint32_t bpi = id[j * THREADS];
+                    const uint32_t r = (j + 1 < len) ? jtk_bp_lookup(L.bp, bpi & 0xFFFFu) : JTK_RANK_NONE;
+                    rk[j * THREADS] = (r != JTK_RANK_NONE) ? ((r << 6) | (uint32_t)j) : KL_NONE;
+                    id[j * THREADS] = L.brank[(bpi >> 8) & 255u];
+                } else rk[j * THREADS] = KL_NONE;
+            }
+            const M one = 1;
+            const M alive0 = (len >= (int)(8 * sizeof(M))) ? ~(M)0 : ((one << len) - one);
+            alive = lean_steps<SLOTS, THREADS, false, M>(id, rk, alive0, reinterpret_cast<const uint8_t*>(t.pairs.buckets), t.pairs.bits);
+        }
+
+        // ---- emit (:270-273): one result word per piece; more than seven tokens go to htok
+        const uint32_t c = sizeof(M) == 8 ? (uint32_t)__popcll((uint64_t)alive) : (uint32_t)__popc((uint32_t)alive);
+        if (have) {
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = (c - 1u) << 24;
+            if (c <= 7u) {
+                M m = alive;
+                uint32_t tk[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    const uint32_t j = m ? (sizeof(M) == 8 ? (uint32_t)jtk_ctz64((uint64_t)m) : (uint32_t)__builtin_ctz((uint32_t)m)) : 0u;
+                    tk[i] = m ? id[j * THREADS] : 0u;
+                    m &= m - (M)1;
+                }
+                // 17 bits each from bit 0: token i at bit 17 * i
+                r0 = tk[0] | (tk[1] << 17);
+                r1 = (tk[1] >> 15) | (tk[2] << 2) | (tk[3] << 19);
+                r2 = (tk[3] >> 13) | (tk[4] << 4) | (tk[5] << 21);
+                r3 |= (tk[5] >> 11) | (tk[6] << 6);
+            } else {
+                uint32_t* dst = w.htok + pos;
+                uint32_t idx = 0;
+                for (M m = alive; m;) {
+                    const uint32_t j = sizeof(M) == 8 ? (uint32_t)jtk_ctz64((uint64_t)m) : (uint32_t)__builtin_ctz((uint32_t)m);
+                    m &= m - (M)1;
+                    dst[idx++] = id[j * THREADS];
+                }
+            }
+            qd[qi] = make_uint4(r0, r1, r2, r3);
+        }
+        // token counts per tile: entries of a tile are consecutive, so a wave sees a few runs of equal tiles; the first
+        // lane of each run adds the run's sum
+        {
+            const int64_t tile = have ? pos / T : -1;
+            const uint32_t cc = have ? c : 0u;
+            const uint32_t inc = wave_incl_scan(cc);
+            const uint32_t tlo = (uint32_t)tile, thi = (uint32_t)((uint64_t)tile >> 32);
+            const bool head = lane == 0 || (uint32_t)__shfl_up((int)tlo, 1) != tlo || (uint32_t)__shfl_up((int)thi, 1) != thi;
+            const uint64_t heads = __ballot(head);
+            const uint64_t later = heads & ~((2ull << lane) - 1ull);                  // run heads after this lane
+            const int last = later ? jtk_ctz64(later) - 1 : 63;                        // last lane of this lane's run
+            const uint32_t run_end = (uint32_t)__shfl((int)inc, last);
+            if (head && have) {
+                const uint32_t sum = run_end - (inc - cc);
+                if (sum) atomicAdd(&w.tile_tot[tile], sum);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(ML_THREADS) k_bpe_merge_lean(JtkWork w, JtkDeviceTables t) {
+    __shared__ uint32_t s_id[16384];
+    __shared__ uint32_t s_rk[16384];
+    __shared__ uint64_t s_bpbits[1024];
+    __shared__ uint32_t s_bpranks[JTK_BP_MAX];
+    __shared__ uint16_t s_bpcum[1024];
+    __shared__ uint32_t s_brank[256];
+    const int tid = threadIdx.x;
+    const int shard = blockIdx.x % JTK_Q_SHARDS;
+    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS;
+    const uint32_t n0 = w.q_count[0 * JTK_Q_SHARDS + shard], n1 = w.q_count[1 * JTK_Q_SHARDS + shard], n2 = w.q_count[2 * JTK_Q_SHARDS + shard];
+    const bool w0 = kq * (uint32_t)ML_THREADS < n0, w1 = kq * (uint32_t)(ML_THREADS / 2) < n1, w2 = kq * (uint32_t)(ML_THREADS / 4) < n2;
+    if (!(w0 || w1 || w2)) return;
+    s_bpbits[tid] = t.bp.bits[tid];
+    s_bpcum[tid] = t.bp.cum[tid];
+    for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
+    if (tid < 256) s_brank[tid] = t.byte_rank[tid];
+    __syncthreads();
+    const LeanLds L{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
+    if (w0) lean_bin<16, ML_THREADS, 0>(w, t, L, n0);
+    if (w1) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 1>(w, t, L, n1); }
+    if (w2) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 2>(w, t, L, n2); }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -634,7 +943,8 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
     const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
     const uint32_t count = L.count[BIN];
     if ((uint64_t)kq * M_CHUNK >= count) return;
-    uint64_t* const queue = w.q[BIN] + (int64_t)shard * w.q_cap[BIN];     // entries are read in aligned pairs
+    const uint64_t* const queue = w.qm[BIN] + (int64_t)shard * w.q_cap[BIN];     // entries are read in aligned pairs
+    uint4* const results = w.qd[BIN] + (int64_t)shard * w.q_cap[BIN];
 
     const JtkBpLds bp{L.bpbits, L.bpcum, L.bpranks};
     const JtkPairTable pt = t.pairs;
@@ -650,7 +960,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
 #endif
     constexpr int BATCH = JTK_EXPAND_BATCH, EMIT_BATCH = JTK_EMIT_BATCH;   // lanes that have to wait before the divergent steps run
     int st = ST_NEED;
-    uint32_t qi = 0, slot = 0;
+    uint32_t qi = 0;
     int64_t pos = 0;
     int len = 0, tpart = 0;
     constexpr int NW = (SLOTS + 63) / 64;
@@ -722,7 +1032,6 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
             const uint64_t entry = (qi & 1u) ? (((uint64_t)v0.w << 32) | v0.z) : (((uint64_t)v0.y << 32) | v0.x);
             pos = (int64_t)(entry & JTK_QE_POS_MASK);
             len = (int)((entry >> JTK_QE_LEN_SHIFT) & 255u) + 1;
-            slot = (uint32_t)(entry >> JTK_QE_IDX_SHIFT) & 1023u;
             tpart = 0;
             st = ST_TEXT;
         } else if (st == ST_TEXT) {
@@ -803,21 +1112,17 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
             }
         }
         // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work.  The result of a
-        // piece is ONE 16-byte word in its fixed result slot (tile, bin, index): count - 1 in the top byte and, if the
-        // piece became at most 7 tokens (nearly all do), the token ids, 17 bits each.  Longer results, and pieces beyond
-        // the tile's slots, leave their tokens in htok, packed from the piece's first byte position.  The count also
-        // replaces the queue entry, where k_tile_counts sums it.
+        // piece is ONE 16-byte word at its queue index: count - 1 in the top byte and, if the piece became at most 7
+        // tokens, the token ids, 17 bits each.  Longer results leave their tokens in htok, packed from the piece's
+        // first byte position.  The count is added to the tile's token total.
         const uint64_t b_emit = __ballot(st == ST_EMIT);
         if (b_emit && (__popcll(b_emit) >= EMIT_BATCH || !b_merge)) {
             if (st == ST_EMIT) {
                 uint32_t c = 0;
 #pragma unroll
                 for (int k = 0; k < NW; k++) c += (uint32_t)__popcll(alive[k]);
-                constexpr uint32_t RCAP = BIN == 0 ? JTK_RES_CAP0 : BIN == 1 ? JTK_BIN_CAP1 : BIN == 2 ? JTK_BIN_CAP2 : BIN == 3 ? JTK_BIN_CAP3 : JTK_BIN_CAP4;
-                constexpr int ROFF = BIN == 0 ? R_OFF0 : BIN == 1 ? R_OFF1 : BIN == 2 ? R_OFF2 : BIN == 3 ? R_OFF3 : R_OFF4;
-                const bool slotted = slot < RCAP;
                 uint64_t lo = 0, hi = (uint64_t)(c - 1) << 56;
-                if (slotted && c <= 7) {
+                if (c <= 7) {
                     uint32_t sh = 0;
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
@@ -832,21 +1137,18 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
                     }
                 } else {
                     uint32_t* dst = w.htok + pos;
-                    dst[0] = id[0] | (c << JTK_HT_CNT_SHIFT);                    // part 0 is never merged away
                     uint32_t idx = 0;
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
-                        for (uint64_t m = alive[k] & ~(uint64_t)(k == 0); m;) {
+                        for (uint64_t m = alive[k]; m;) {
                             const int j = k * 64 + jtk_ctz64(m);
                             m &= m - 1;
-                            dst[++idx] = id[j * THREADS];
+                            dst[idx++] = id[j * THREADS];
                         }
                     }
                 }
-                if (slotted)
-                    reinterpret_cast<uint4*>(w.qres)[(pos / T) * JTK_RES_PER_TILE + ROFF + slot] =
-                        make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-                queue[qi] = (uint64_t)(c - 1) << JTK_QE_CNT_SHIFT;                // dense: k_tile_counts sums the counts
+                results[qi] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                atomicAdd(&w.tile_tot[pos / T], c);
                 st = ST_NEED;
             }
         }
@@ -924,7 +1226,7 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
         }
         if (lane == 0) {
             w.htok[lp.start] = s_id[0] | (total << JTK_HT_CNT_SHIFT);
-            atomicAdd(&w.tile_extra[lp.start / T], total);
+            atomicAdd(&w.tile_tot[lp.start / T], total);
         }
         wave_lds_fence();
     }
@@ -1046,7 +1348,7 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
         if (lane == 0) {
             gid[0] = first | ((uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT);
             w.giant_cnt[gi] = total;
-            atomicAdd(&w.tile_extra[lp.start / T], total);
+            atomicAdd(&w.tile_tot[lp.start / T], total);
         }
     }
     __syncthreads();
@@ -1068,22 +1370,22 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     __shared__ uint32_t s_next[JTK_NBINS];
     __shared__ uint32_t s_count[JTK_NBINS + 3];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 1024; i += 1024) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
-    for (int i = tid; i < JTK_BP_MAX; i += 1024) s_bpranks[i] = t.bp.ranks[i];
-    for (int i = tid; i < 256; i += 1024) s_brank[i] = t.byte_rank[i];
     if (tid < JTK_NBINS) {
         s_next[tid] = 0;
-        s_count[tid] = w.q_count[tid * JTK_Q_SHARDS + blockIdx.x % JTK_Q_SHARDS];
+        s_count[tid] = tid <= 2 ? 0u : w.q_count[tid * JTK_Q_SHARDS + blockIdx.x % JTK_Q_SHARDS];   // bins 0..2: k_bpe_merge_lean
     }
     if (tid == JTK_NBINS) s_count[JTK_NBINS] = *w.mid_count;
     if (tid == JTK_NBINS + 1) s_count[JTK_NBINS + 1] = *w.long_count;
     if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = w.result->n_giant;
     __syncthreads();
+    // ordinary text has no piece above 16 bytes in most workgroups' shards: nothing to stage, nothing to do
+    if (!(s_count[1] | s_count[2] | s_count[3] | s_count[4] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2])) return;
+    for (int i = tid; i < 1024; i += 1024) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
+    for (int i = tid; i < JTK_BP_MAX; i += 1024) s_bpranks[i] = t.bp.ranks[i];
+    for (int i = tid; i < 256; i += 1024) s_brank[i] = t.byte_rank[i];
+    __syncthreads();
     const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
     // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
-    merge_bin<16, 1024, 0>(w, t, L);
-    if (s_count[1]) { __syncthreads(); merge_bin<32, 512, 1>(w, t, L); }
-    if (s_count[2]) { __syncthreads(); merge_bin<64, 256, 2>(w, t, L); }
     if (s_count[3]) { __syncthreads(); merge_bin<128, 128, 3>(w, t, L); }
     if (s_count[4]) { __syncthreads(); merge_bin<256, 64, 4>(w, t, L); }
     // pieces of 257..512 bytes: every wave of the grid takes pieces, parts in its own 2 x 512 words
@@ -1107,45 +1409,12 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// tile_counts / tile_scan: tokens per tile (resolved pieces were counted by piece_resolve; the merge
-// kernels left each merged piece's count in its queue entry) and their exclusive scan.  Two small
-// kernels: a device-wide single-pass scan (decoupled look-back) was measured 4x slower here, because
-// descriptors shared between workgroups on different XCDs have to bypass the per-XCD L2s.
-//   tile_counts: 16 lanes per tile sum the tile's queue slices; one atomic per 64 tiles into the
-//                sum of its chunk of SCAN_CHUNK tiles
-//   tile_scan:   one workgroup per chunk: base = sum of the earlier chunks' sums, then a local scan
+// tile_scan: exclusive scan of the tokens per tile (tile_tot: the resolved pieces counted by piece_resolve plus
+// what the merge kernels added).  One workgroup per chunk of SCAN_CHUNK tiles; its base is the sum of all earlier
+// tiles, which it adds up itself (4 bytes per tile from L2: less than a descriptor hand-off between workgroups on
+// different XCDs would cost -- a single-pass look-back scan was measured 4x slower here).
 // ---------------------------------------------------------------------------------------------------
 constexpr int SCAN_CHUNK = 4096;
-
-__global__ void __launch_bounds__(1024) k_tile_counts(JtkWork w) {
-    // 16 lanes per tile, 64 tiles per workgroup
-    __shared__ uint32_t s_sum[16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane & 15;
-    const int64_t tile = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 4);
-    const bool live = tile < w.n_tiles;
-    const uint32_t meta = live ? w.q_meta[tile * 16 + g] : 0u;        // lanes 0..4: base per bin, lanes 8..12: count per bin
-    uint32_t c = 0;
-    const int gl = lane & ~15;
-#pragma unroll
-    for (int k = 0; k < JTK_NBINS; k++) {
-        const uint32_t qb = (uint32_t)__shfl((int)meta, gl + k), nq = (uint32_t)__shfl((int)meta, gl + 8 + k);
-        const uint64_t* q = w.q[k] + (tile % JTK_Q_SHARDS) * w.q_cap[k] + qb;
-        for (uint32_t i = g; i < nq; i += 16) c += ((uint32_t)(q[i] >> JTK_QE_CNT_SHIFT) & 255u) + 1u;
-    }
-    for (int d = 8; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
-    if (live && g == 0) {
-        c += w.tile_cnt[tile] + w.tile_extra[tile];
-        w.tile_tot[tile] = c;
-    } else c = 0;
-    for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
-    if (lane == 0) s_sum[wv] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int k = 0; k < 16; k++) t += s_sum[k];
-        if (t) atomicAdd((unsigned long long*)&w.chunk_sum[((int64_t)blockIdx.x * 64) / SCAN_CHUNK], (unsigned long long)t);
-    }
-}
 
 __global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
     __shared__ uint64_t s_part[16];
@@ -1154,7 +1423,11 @@ __global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
     const int64_t chunk = blockIdx.x;
     // tokens before this chunk
     uint64_t b = 0;
-    for (int64_t c = tid; c < chunk; c += 1024) b += w.chunk_sum[c];
+    {
+        const int64_t nb = chunk * SCAN_CHUNK;
+        const uint4* t4 = reinterpret_cast<const uint4*>(w.tile_tot);
+        for (int64_t i = tid; i < nb / 4; i += 1024) { const uint4 v = t4[i]; b += (uint64_t)v.x + v.y + v.z + v.w; }
+    }
     for (int d = 32; d >= 1; d >>= 1) {
         const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), d);
         b += ((uint64_t)hi << 32) | lo;
@@ -1222,9 +1495,9 @@ constexpr int PACK_STAGE = 1024;               // tokens of a tile assembled in 
 
 __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     // ONE WAVE PER TILE, no workgroup barriers.  A wave keeps a whole tile in flight: 8 list entries per lane, the head
-    // of the tile's merge results and the document mask are all requested before the first wait.  The tile's tokens are
-    // assembled in LDS (the few multi-token pieces make sparse writes, cheap there and expensive in memory) and leave
-    // in full 256-byte stores.
+    // of the tile's merge results (they are dense: the tile's slice of each bin's queue) and the document mask are all
+    // requested before the first wait.  The tile's tokens are assembled in LDS (the few multi-token pieces make sparse
+    // writes, cheap there and expensive in memory) and leave in full 256-byte stores.
     __shared__ uint4 s_qe[128];
     __shared__ uint64_t s_dm[TW];
     __shared__ uint32_t s_out[PACK_STAGE];
@@ -1233,6 +1506,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     const int64_t B = tile * T;
     const int np = (int)w.tile_np[tile];
     const uint32_t total = w.tile_tot[tile];
+    const uint32_t meta = lane < 16 ? w.q_meta[tile * 16 + lane] : 0u;    // lanes 0..4: start per bin, lanes 8..12: count per bin
     const bool stage = total <= (uint32_t)PACK_STAGE;
     const bool store = w.count_only == 0;     // countTokens(): offsets only, no token ids
     const uint32_t* plist = w.plist + B;
@@ -1244,14 +1518,16 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
         const int64_t dwd = (B >> 6) + lane;
         s_dm[lane] = (dwd < w.n_words) ? w.docmask[dwd] : 0ull;
     }
-    // the head of the tile's result slots, read speculatively (no dependence on the list): the first 64 of bin 0
-    // and the first 16 of bins 1..4; slots beyond are read on demand
-    const uint4* qres = reinterpret_cast<const uint4*>(w.qres) + tile * JTK_RES_PER_TILE;
-    {
-        const int b = 1 + (lane >> 4);
-        const int ro = b == 1 ? R_OFF1 : b == 2 ? R_OFF2 : b == 3 ? R_OFF3 : R_OFF4;
-        s_qe[lane] = qres[lane];
-        s_qe[64 + lane] = qres[ro + (lane & 15)];
+    // the tile's merge results: the first 64 of bin 0 and the first 16 of bins 1..4 are staged, others are read on demand
+    const int64_t shard = tile % JTK_Q_SHARDS;
+    const uint32_t qb0 = (uint32_t)__shfl((int)meta, 0), nq0 = (uint32_t)__shfl((int)meta, 8);
+    const uint4* const res0 = w.qd[0] + shard * w.q_cap[0] + qb0;
+    if ((uint32_t)lane < nq0) s_qe[lane] = res0[lane];
+    const uint32_t nq_hi = (uint32_t)__shfl((int)meta, 9) | (uint32_t)__shfl((int)meta, 10) | (uint32_t)__shfl((int)meta, 11) | (uint32_t)__shfl((int)meta, 12);
+    if (nq_hi) {                                                          // wave-uniform; rare in ordinary text
+        const int bq = 1 + (lane >> 4);
+        const uint32_t qb = (uint32_t)__shfl((int)meta, bq), nq = (uint32_t)__shfl((int)meta, 8 + bq);
+        if ((uint32_t)(lane & 15) < nq) s_qe[64 + lane] = (w.qd[bq] + shard * w.q_cap[bq] + qb)[lane & 15];
     }
     wave_lds_fence();
     uint32_t run = 0;
@@ -1262,8 +1538,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
         const bool hard = (ej & JTK_PL_HARD) != 0;
         const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
         const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
-        const bool slotted = queued && (bin != 0 || qi < (uint32_t)JTK_RES_CAP0);
-        const bool staged = slotted && (bin == 0 ? qi < 64u : qi < 16u);
+        const bool staged = queued && (bin == 0 ? qi < 64u : qi < 16u);
         const uint32_t sidx = staged ? (bin == 0 ? qi : 48u + bin * 16u + qi) : 0u;
         uint4 qe = s_qe[sidx];
         uint32_t c = valid ? (hard ? (qe.w >> 24) + 1u : 1u) : 0u;
@@ -1292,18 +1567,19 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
                 }
             }
         } else {
-            // general case: results beyond the staged head or beyond the tile's slots, results of more than 7 tokens,
-            // pieces merged by the wave / workgroup kernels (htok)
-            if (valid && slotted && !staged) {
-                qe = qres[(bin == 0 ? R_OFF0 : bin == 1 ? R_OFF1 : bin == 2 ? R_OFF2 : bin == 3 ? R_OFF3 : R_OFF4) + qi];
+            // general case: results beyond the staged head, results of more than 7 tokens (tokens in htok), pieces merged
+            // by the wave / workgroup phases (count and tokens in htok)
+            const uint32_t qb = (uint32_t)__shfl((int)meta, (int)(bin < JTK_NBINS ? bin : 0u));   // (all lanes take part)
+            if (valid && queued && !staged) {
+                qe = (w.qd[bin] + shard * w.q_cap[bin] + qb)[qi];
                 c = (qe.w >> 24) + 1u;
-            } else if (valid && hard && !slotted) c = hard_count(w, B + off);       // count in the htok header
+            } else if (valid && hard && !queued) c = hard_count(w, B + off);        // count in the htok header
             const uint32_t inc = wave_incl_scan(c);
             pre = run + inc - c;
             run += (uint32_t)__shfl((int)inc, 63);
             if (valid) {
                 if (!hard) STORE(out[pre] = ej & JTK_HT_ID_MASK);
-                else if (slotted && c <= 7u) {
+                else if (queued && c <= 7u) {
                     STORE(out[pre] = qe.x & JTK_HT_ID_MASK);
                     if (c > 1u) STORE(out[pre + 1] = res_tok<1>(qe));
                     if (c > 2u) STORE(out[pre + 2] = res_tok<2>(qe));
@@ -1367,10 +1643,10 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
     hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
+    hipLaunchKernelGGL(k_bpe_merge_lean, dim3(JTK_Q_SHARDS * ML_WGS_PER_SHARD), dim3(ML_THREADS), 0, s, w, t);
     hipLaunchKernelGGL(k_bpe_merge_all, dim3(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD), dim3(1024), 0, s, w, t);
 }
-void jtk_launch_tile_counts_scan(const JtkWork& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((w.n_tiles + 63) / 64)), dim3(1024), 0, s, w);
+void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((w.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK)), dim3(1024), 0, s, w);
 }
 void jtk_launch_pack(const JtkWork& w, hipStream_t s) {

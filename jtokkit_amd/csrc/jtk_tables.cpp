@@ -9,6 +9,7 @@
 #include "jtk_tables.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 #include "../../include/jtokkit_amd.h"
@@ -51,6 +52,68 @@ bool b64decode(const char* s, size_t n, std::string& out) {
 inline bool is_ws(char c) { return c == ' ' || (c >= 9 && c <= 13); }
 
 }  // namespace
+
+// Primary-first two-choice placement (jtk_common.h): item i may live in bucket h1[i] (primary) or h2[i]; a bucket holds
+// `cap` items.  Items arrive in the order given -- the callers pass them by ascending rank, i.e. most frequent first, so
+// the frequent entries keep their primary buckets -- and stay in the primary bucket if it has room.  The others go to
+// their secondary bucket; when that is full too, a resident of either bucket that can move to a free place does so,
+// else residents are kicked along a walk (the later, rarer item of a bucket is the one that moves).
+// where[i] = the bucket of item i.
+static bool place_primary_first(const std::vector<uint32_t>& h1, const std::vector<uint32_t>& h2, uint32_t nb, int cap,
+                                std::vector<uint32_t>& where) {
+    const size_t n = h1.size();
+    where.assign(n, 0xFFFFFFFFu);
+    std::vector<std::vector<uint32_t>> res(nb);
+    std::vector<uint32_t> pending;
+    for (size_t i = 0; i < n; i++) {
+        if ((int)res[h1[i]].size() < cap) { res[h1[i]].push_back((uint32_t)i); where[i] = h1[i]; }
+        else pending.push_back((uint32_t)i);
+    }
+    auto other = [&](uint32_t item, uint32_t bucket) { return h1[item] == bucket ? h2[item] : h1[item]; };
+    auto move_out = [&](uint32_t bucket, size_t k, uint32_t to) {     // resident k of `bucket` moves to `to` (which has room)
+        const uint32_t v = res[bucket][k];
+        res[bucket][k] = res[bucket].back(); res[bucket].pop_back();
+        res[to].push_back(v); where[v] = to;
+    };
+    for (uint32_t start : pending) {
+        uint32_t cur = start;
+        bool placed = false;
+        uint32_t target = h2[cur];
+        for (int kick = 0; kick < 20000 && !placed; kick++) {
+            if ((int)res[target].size() < cap) { res[target].push_back(cur); where[cur] = target; placed = true; break; }
+            // one-step moves: a resident of either of cur's buckets whose other bucket has room
+            const uint32_t cand[2] = {h1[cur], h2[cur]};
+            for (int c = 0; c < 2 && !placed; c++) {
+                auto& r = res[cand[c]];
+                for (size_t k = 0; k < r.size() && !placed; k++) {
+                    const uint32_t to = other(r[k], cand[c]);
+                    if (to != cand[c] && (int)res[to].size() < cap) {
+                        move_out(cand[c], k, to);
+                        res[cand[c]].push_back(cur); where[cur] = cand[c];
+                        placed = true;
+                    }
+                }
+            }
+            if (placed) break;
+            // kick the latest (rarest) resident of the target bucket and continue with it
+            size_t v = 0;
+            for (size_t k = 1; k < res[target].size(); k++) if (res[target][k] > res[target][v]) v = k;
+            const uint32_t victim = res[target][v];
+            res[target][v] = cur; where[cur] = target;
+            cur = victim;
+            target = other(cur, target);
+        }
+        if (!placed) return false;
+    }
+    // items sitting in their secondary bucket although their primary has room again go home
+    for (size_t i = 0; i < n; i++) {
+        if (where[i] != h1[i] && (int)res[h1[i]].size() < cap) {
+            auto& r = res[where[i]];
+            for (size_t k = 0; k < r.size(); k++) if (r[k] == (uint32_t)i) { move_out(where[i], k, h1[i]); break; }
+        }
+    }
+    return true;
+}
 
 int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len,
                      const char* const* special_literals, const int32_t* special_ids, int n_specials,
@@ -121,40 +184,31 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
     }
     t.n_pairs = (int64_t)pairs.size();
-    // two-choice cuckoo, two slots per bucket; random-walk insertion.  Slot load ~0.72: cl100k's 233k
-    // pairs take 2.6 MB, leaving room in a 4 MiB L2 for the streams that pass through it.
+    std::sort(pairs.begin(), pairs.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
+        return x.second != y.second ? x.second < y.second : x.first < y.first; });      // by rank: frequent merges first
+    // two-choice cuckoo, two slots per bucket, primary first.  Slot load 0.5: one bucket in twelve turns a key away.
     {
-        double load = 0.72;
+        double load = 0.5;
         for (;; load *= 0.9) {
             const uint32_t nb = (uint32_t)((double)pairs.size() / (2.0 * load)) + 16;
-            std::vector<uint64_t> slots((size_t)2 * nb, JTK_PAIR_EMPTY);
-            uint32_t rng = 0x12345u;
-            bool ok = true;
-            for (auto& p : pairs) {
-                uint64_t cur = (p.first << 30) | p.second;
-                bool placed = false;
-                for (int kick = 0; kick < 5000 && !placed; kick++) {
-                    const uint64_t key = cur >> 30;
-                    const uint32_t a = (uint32_t)(key >> JTK_ID_BITS), b = (uint32_t)(key & ((1u << JTK_ID_BITS) - 1));
-                    const uint32_t bk[2] = {jtk_pair_hash(a, b, nb), jtk_pair_hash2(a, b, nb)};
-                    for (int c = 0; c < 2 && !placed; c++)
-                        for (int sidx = 0; sidx < 2 && !placed; sidx++)
-                            if (slots[(size_t)bk[c] * 2 + sidx] == JTK_PAIR_EMPTY) { slots[(size_t)bk[c] * 2 + sidx] = cur; placed = true; }
-                    if (!placed) {
-                        rng = rng * 1664525u + 1013904223u;
-                        const size_t victim = (size_t)bk[(rng >> 16) & 1] * 2 + ((rng >> 17) & 1);
-                        std::swap(cur, slots[victim]);
-                    }
-                }
-                if (!placed) { ok = false; break; }
+            std::vector<uint32_t> h1(pairs.size()), h2(pairs.size()), where;
+            for (size_t i = 0; i < pairs.size(); i++) {
+                const uint32_t a = (uint32_t)(pairs[i].first >> JTK_ID_BITS), b = (uint32_t)(pairs[i].first & ((1u << JTK_ID_BITS) - 1));
+                h1[i] = jtk_pair_hash(a, b, nb);
+                h2[i] = jtk_pair_hash2(a, b, nb);
             }
-            if (!ok) continue;
+            if (!place_primary_first(h1, h2, nb, 2, where)) continue;
             t.pair_bits = nb;
-            t.pair_buckets.resize(nb);
-            for (size_t k = 0; k < t.pair_buckets.size(); k++) {
-                const uint64_t s0 = slots[2 * k], s1 = slots[2 * k + 1];
-                t.pair_buckets[k] = JtkPairBucket{(uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32)};
+            t.pair_buckets.assign(nb, JtkPairBucket{0xFFFFFFFFu, 0xDFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
+            t.pair_displaced = 0;
+            for (size_t i = 0; i < pairs.size(); i++) {
+                JtkPairBucket& bk = t.pair_buckets[where[i]];
+                const uint32_t kw = (uint32_t)pairs[i].first, rw = pairs[i].second | ((uint32_t)(pairs[i].first >> 32) << 30);
+                if (bk.k0 == 0xFFFFFFFFu && (bk.r0 | JTK_PAIR_OVERFLOW) == 0xFFFFFFFFu) { bk.k0 = kw; bk.r0 = rw | (bk.r0 & JTK_PAIR_OVERFLOW); }
+                else { bk.k1 = kw; bk.r1 = rw; }
             }
+            for (size_t i = 0; i < pairs.size(); i++)
+                if (where[i] != h1[i]) { t.pair_buckets[h1[i]].r0 |= JTK_PAIR_OVERFLOW; t.pair_displaced++; }
             break;
         }
     }
@@ -173,6 +227,7 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         shorts.push_back(JtkTok8Slot{lo, hi, kv.second, (uint32_t)T.size()});
     }
     t.n_tok8 = (int64_t)shorts.size();
+    std::sort(shorts.begin(), shorts.end(), [](const JtkTok8Slot& x, const JtkTok8Slot& y) { return x.id < y.id; });   // frequent first
     // Bytes b0 b1 that never sit next to each other inside any table entry can never end up in one part:
     // every merge result is a table entry.  bytePairMerge therefore never merges across such a position,
     // the sub-pieces on either side merge independently, and the split kernel may cut there.
@@ -199,28 +254,21 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
     }
     {
-        double load = 0.45;
+        double load = 0.4;
         for (;; load *= 0.9) {
             const uint32_t ns = (uint32_t)((double)shorts.size() / load) + 16;
-            std::vector<JtkTok8Slot> slots(ns, JtkTok8Slot{0, 0, 0, 0});
-            uint32_t rng = 0x9876u;
-            bool ok = true;
-            for (auto cur : shorts) {
-                bool placed = false;
-                for (int kick = 0; kick < 5000 && !placed; kick++) {
-                    const uint32_t h[2] = {jtk_tok8_hash(cur.lo, cur.hi, cur.len, ns), jtk_tok8_hash2(cur.lo, cur.hi, cur.len, ns)};
-                    for (int c = 0; c < 2 && !placed; c++)
-                        if (slots[h[c]].len == 0) { slots[h[c]] = cur; placed = true; }
-                    if (!placed) {
-                        rng = rng * 1664525u + 1013904223u;
-                        std::swap(cur, slots[h[(rng >> 16) & 1]]);
-                    }
-                }
-                if (!placed) { ok = false; break; }
+            std::vector<uint32_t> h1(shorts.size()), h2(shorts.size()), where;
+            for (size_t i = 0; i < shorts.size(); i++) {
+                h1[i] = jtk_tok8_hash(shorts[i].lo, shorts[i].hi, shorts[i].len, ns);
+                h2[i] = jtk_tok8_hash2(shorts[i].lo, shorts[i].hi, shorts[i].len, ns);
             }
-            if (!ok) continue;
+            if (!place_primary_first(h1, h2, ns, 1, where)) continue;
             t.tok8_bits = ns;
-            t.tok8 = slots;
+            t.tok8.assign(ns, JtkTok8Slot{0, 0, 0, 0});
+            t.tok8_displaced = 0;
+            for (size_t i = 0; i < shorts.size(); i++) t.tok8[where[i]] = shorts[i];
+            for (size_t i = 0; i < shorts.size(); i++)
+                if (where[i] != h1[i]) { t.tok8[h1[i]].len |= JTK_TOK_OVERFLOW; t.tok8_displaced++; }
             break;
         }
     }
@@ -235,29 +283,21 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
             mids.push_back(e);
         }
         t.n_tok16 = (int64_t)mids.size();
-        double load = 0.45;
+        std::sort(mids.begin(), mids.end(), [](const JtkTok16Slot& x, const JtkTok16Slot& y) { return x.id < y.id; });
+        double load = 0.4;
         for (;; load *= 0.9) {
             const uint32_t ns = (uint32_t)((double)mids.size() / load) + 16;
-            std::vector<JtkTok16Slot> slots(ns, JtkTok16Slot{{0, 0, 0, 0}, 0, 0, 0, 0});
-            uint32_t rng = 0x1357u;
-            bool ok = true;
-            for (auto cur : mids) {
-                bool placed = false;
-                for (int kick = 0; kick < 5000 && !placed; kick++) {
-                    const uint32_t h[2] = {jtk_tok16_hash(cur.k[0], cur.k[1], cur.k[2], cur.k[3], cur.len, ns),
-                                           jtk_tok16_hash2(cur.k[0], cur.k[1], cur.k[2], cur.k[3], cur.len, ns)};
-                    for (int c = 0; c < 2 && !placed; c++)
-                        if (slots[h[c]].len == 0) { slots[h[c]] = cur; placed = true; }
-                    if (!placed) {
-                        rng = rng * 1664525u + 1013904223u;
-                        std::swap(cur, slots[h[(rng >> 16) & 1]]);
-                    }
-                }
-                if (!placed) { ok = false; break; }
+            std::vector<uint32_t> h1(mids.size()), h2(mids.size()), where;
+            for (size_t i = 0; i < mids.size(); i++) {
+                h1[i] = jtk_tok16_hash(mids[i].k[0], mids[i].k[1], mids[i].k[2], mids[i].k[3], mids[i].len, ns);
+                h2[i] = jtk_tok16_hash2(mids[i].k[0], mids[i].k[1], mids[i].k[2], mids[i].k[3], mids[i].len, ns);
             }
-            if (!ok) continue;
+            if (!place_primary_first(h1, h2, ns, 1, where)) continue;
             t.tok16_n = ns;
-            t.tok16 = slots;
+            t.tok16.assign(ns, JtkTok16Slot{{0, 0, 0, 0}, 0, 0, 0, 0});
+            for (size_t i = 0; i < mids.size(); i++) t.tok16[where[i]] = mids[i];
+            for (size_t i = 0; i < mids.size(); i++)
+                if (where[i] != h1[i]) t.tok16[h1[i]].len |= JTK_TOK_OVERFLOW;
             break;
         }
     }

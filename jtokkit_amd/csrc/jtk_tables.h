@@ -30,9 +30,10 @@ struct JtkHostTables {
     std::vector<uint64_t> bp_bits;               // [1024]
     std::vector<uint16_t> bp_cum;                // [1024]
     std::vector<uint32_t> bp_ranks;              // [n_bp] (padded to JTK_BP_MAX)
-    std::vector<JtkPairBucket> pair_buckets;     // two-choice cuckoo (left,right) -> rank table
+    std::vector<JtkPairBucket> pair_buckets;     // two-choice cuckoo, primary first: (left,right) -> rank table
     uint32_t pair_bits = 0;
     int64_t n_pairs = 0;
+    int64_t pair_displaced = 0, tok8_displaced = 0;   // entries living in their secondary bucket
     int64_t n_tokens = 0;
     uint32_t max_id = 0;
 };

@@ -186,12 +186,13 @@ int64_t sim_tok8_lookup(void* h, const uint8_t* piece, int len) {
     if (len < 1 || len > 8) return -1;
     uint32_t lo = 0, hi = 0;
     for (int k = 0; k < len; k++) { if (k < 4) lo |= (uint32_t)piece[k] << (8 * k); else hi |= (uint32_t)piece[k] << (8 * (k - 4)); }
-    const JtkTok8Slot& s1 = t->tok8[jtk_tok8_hash(lo, hi, (uint32_t)len, t->tok8_bits)];
-    const JtkTok8Slot& s2 = t->tok8[jtk_tok8_hash2(lo, hi, (uint32_t)len, t->tok8_bits)];
-    if (s1.len == (uint32_t)len && s1.lo == lo && s1.hi == hi) return s1.id;
-    if (s2.len == (uint32_t)len && s2.lo == lo && s2.hi == hi) return s2.id;
-    return -1;
+    const JtkTok8Table tt{t->tok8.data(), t->tok8_bits};
+    const uint32_t id = jtk_tok8_find(tt, lo, hi, (uint32_t)len);
+    return id == JTK_RANK_NONE ? -1 : (int64_t)id;
 }
+// fraction of the pair-table / tok8 entries that live in their secondary bucket (lookups of those cost two fetches)
+double sim_pair_displaced(void* h) { JtkHostTables* t = (JtkHostTables*)h; return (double)t->pair_displaced / (double)t->n_pairs; }
+double sim_tok8_displaced(void* h) { JtkHostTables* t = (JtkHostTables*)h; return (double)t->tok8_displaced / (double)t->n_tok8; }
 int sim_tok8_bits(void* h) { return (int)((JtkHostTables*)h)->tok8_bits; }
 int64_t sim_tok8_count(void* h) { return ((JtkHostTables*)h)->n_tok8; }
 // fraction of buckets' slots in use
@@ -199,8 +200,8 @@ double sim_tables_avg_probe(void* h) {
     JtkHostTables* t = (JtkHostTables*)h;
     double used = 0;
     for (auto& b : t->pair_buckets) {
-        if (!(b.s0lo == 0xFFFFFFFFu && b.s0hi == 0xFFFFFFFFu)) used++;
-        if (!(b.s1lo == 0xFFFFFFFFu && b.s1hi == 0xFFFFFFFFu)) used++;
+        if (!(b.k0 == 0xFFFFFFFFu && b.r0 == 0xFFFFFFFFu)) used++;
+        if (!(b.k1 == 0xFFFFFFFFu && b.r1 == 0xFFFFFFFFu)) used++;
     }
     return used / (2.0 * (double)t->pair_buckets.size());
 }
