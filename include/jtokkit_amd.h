@@ -54,9 +54,19 @@ enum {
     JTK_ENCODE_VALIDATE_UTF8 = 2u,/* also check every document is well-formed UTF-8 (what String.getBytes(UTF_8)
                                      produces); offenders get status JTK_ERR_BAD_UTF8.  Without the flag the
                                      input is trusted: malformed bytes are encoded as the bytes they are. */
-    JTK_ENCODE_COUNT_ONLY = 4u    /* Encoding.countTokens() / countTokensOrdinary() (GptBytePairEncoding.java:122-129) for
+    JTK_ENCODE_COUNT_ONLY = 4u,   /* Encoding.countTokens() / countTokensOrdinary() (GptBytePairEncoding.java:122-129) for
                                      the whole batch: token offsets (tok_off[d + 1] - tok_off[d] = the count) and
                                      status, but no token ids -- fetch with tokens == NULL */
+    JTK_ENCODE_TO_HOST = 8u       /* jtk_batch_encode only: stream the result to pinned host memory while later chunks
+                                     are still being encoded; read it in place with jtk_batch_host_result() */
+};
+
+/* Options of jtk_batch_set_option.  A batch larger than one chunk is cut into runs of whole documents ("chunks") that flow
+ * through a few scratch sets, each on its own HIP stream: the copies and kernels of consecutive chunks overlap, and the
+ * device scratch is sized by the chunk, not by the batch. */
+enum {
+    JTK_OPT_CHUNK_BYTES = 1,      /* target bytes of text per chunk (default 64 MiB; env JTK_CHUNK_BYTES) */
+    JTK_OPT_CHUNKS_IN_FLIGHT = 2  /* scratch sets / streams, 1..4 (default 2; env JTK_CHUNKS_IN_FLIGHT) */
 };
 
 typedef struct jtk_encoding jtk_encoding;
@@ -97,15 +107,31 @@ int64_t jtk_encoding_pair_count(const jtk_encoding* enc);        /* (left,right)
  */
 int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out);
 void jtk_batch_destroy(jtk_batch* b);
+int jtk_batch_set_option(jtk_batch* b, int option, int64_t value);
 
-/* Host buffers: copies the input to the device, runs the kernels, leaves the result on the device.
+/* Page-locked host memory (hipHostMalloc).  Host buffers handed to jtk_batch_encode are copied by DMA straight from
+ * where they are when they were allocated here (what a Java shim does for its direct ByteBuffers); pageable memory
+ * works too but is staged by the HIP runtime at a fraction of the link's rate. */
+int jtk_host_alloc(size_t bytes, void** out);
+void jtk_host_free(void* p);
+
+/* Host buffers: copies the input to the device chunk by chunk (the copy of a chunk overlaps the kernels of the one
+ * before), runs the kernels, leaves the result on the device (and, with JTK_ENCODE_TO_HOST, in pinned host memory).
  * *n_tokens receives the total token count (this call synchronises). */
 int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs,
                      uint32_t flags, int64_t* n_tokens);
 
+/* After an encode with JTK_ENCODE_TO_HOST: the result in the batch's pinned host buffers (valid until the next encode
+ * on this batch): tokens[n_tokens], tok_off[n_docs + 1], status[n_docs]. */
+int jtk_batch_host_result(jtk_batch* b, const int32_t** tokens, const int64_t** tok_off, const int32_t** status);
+
 /* Device buffers already resident in HBM (what bench.py times).  `stream_or_null` = a hipStream_t
- * to order against, or NULL for the batch's own stream.  With n_tokens == NULL nothing
- * synchronises; query later with jtk_batch_result(). */
+ * to order against, or NULL for the batch's own stream: the whole encode is ordered like one operation on that stream
+ * (inside, the chunks of a large batch run on the batch's own streams, forked from and joined into it).  With
+ * n_tokens == NULL the call does not wait for the result (a batch larger than one chunk waits for the work queued on the
+ * stream BEFORE it, once, to read the chunk boundaries from d_doc_off); query later with jtk_batch_result().
+ * d_utf8 must be 16-byte aligned and readable up to the next multiple of 16 past n_bytes; d_doc_off is checked on the
+ * device: offsets that are out of range or decreasing make JTK_ERR_INVALID_ARGUMENT the batch's worst status. */
 int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* d_doc_off, int64_t n_docs,
                             int64_t n_bytes, uint32_t flags, void* stream_or_null, int64_t* n_tokens);
 

@@ -27,6 +27,9 @@ JTK_PATTERN_CL100K = 1
 JTK_ENCODE_ORDINARY = 1
 JTK_ENCODE_VALIDATE_UTF8 = 2
 JTK_ENCODE_COUNT_ONLY = 4
+JTK_ENCODE_TO_HOST = 8
+JTK_OPT_CHUNK_BYTES = 1
+JTK_OPT_CHUNKS_IN_FLIGHT = 2
 
 # every symbol include/jtokkit_amd.h declares: (restype, argtypes)
 _p = C.c_void_p
@@ -44,6 +47,10 @@ SIGNATURES = {
     "jtk_encoding_pair_count": (_i64, [_p]),
     "jtk_batch_create": (C.c_int, [_p, C.POINTER(_p)]),
     "jtk_batch_destroy": (None, [_p]),
+    "jtk_batch_set_option": (C.c_int, [_p, C.c_int, _i64]),
+    "jtk_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_p)]),
+    "jtk_host_free": (None, [_p]),
+    "jtk_batch_host_result": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "jtk_batch_encode": (C.c_int, [_p, _p, _p, _i64, C.c_uint32, C.POINTER(_i64)]),
     "jtk_batch_encode_device": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_uint32, _p, C.POINTER(_i64)]),
     "jtk_batch_stream": (_p, [_p]),

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -59,14 +60,43 @@ struct jtk_encoding {
     std::vector<uint32_t> tok_len;   // byte length per id (0 = absent), for the maxTokens back-off
 };
 
+// One chunk in flight: a stream and the scratch of the kernels (sized for the largest chunk it has seen).
+struct ChunkSet {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_scan = nullptr;    // this set's tile_scan has run (the next chunk's scan waits for it: token order)
+    hipEvent_t ev_done = nullptr;    // this set's last kernel has run
+    DevBuf zeroed;                   // docmask | list counters | queue counters
+    DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list, giant_list, giant_cnt;
+    JtkWork work{};
+    bool used = false;               // by the current job
+};
+
+constexpr int MAX_SETS = 4;
+
 struct jtk_batch {
     const jtk_encoding* enc = nullptr;
-    hipStream_t stream = nullptr;
-    hipStream_t last_stream = nullptr;
-    DevBuf in_text, in_off;          // staging for the host-buffer entry point
-    DevBuf zeroed;                   // docmask | status | result | list counters | queue counters | pack scan state
-    DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list,
-        giant_list, giant_cnt, tokens, tok_off;
+    hipStream_t stream = nullptr;        // the batch's own main stream
+    hipStream_t last_stream = nullptr;   // main stream of the last job (the caller's, or `stream`)
+    hipStream_t copy_stream = nullptr;   // tokens of finished chunks to pinned host memory (JTK_ENCODE_TO_HOST)
+    hipEvent_t ev_fork = nullptr, ev_copy = nullptr;
+    int64_t* h_info = nullptr;           // pinned, device-visible: per chunk, its first token and the end of its last
+    size_t h_info_cap = 0;
+    ChunkSet set[MAX_SETS];
+    int n_sets = 2;                      // chunks in flight (JTK_OPT_CHUNKS_IN_FLIGHT)
+    int64_t chunk_bytes = (int64_t)64 << 20;   // JTK_OPT_CHUNK_BYTES
+    // the whole batch
+    DevBuf in_text, in_off;          // device copy of host input (host-buffer entry point)
+    DevBuf status, job;              // per document | JtkResult + running token totals per chunk
+    DevBuf tokens, tok_off;
+    DevBuf plan;                     // chunk plan of a device-resident batch
+    int64_t* host_plan = nullptr;    // pinned
+    size_t host_plan_cap = 0;
+    std::vector<int64_t> chunk_doc, chunk_off;
+    // results streamed to pinned host memory (JTK_ENCODE_TO_HOST)
+    int32_t* h_tokens = nullptr; size_t h_tokens_cap = 0;
+    int64_t* h_tok_off = nullptr; size_t h_tok_off_cap = 0;
+    int32_t* h_status = nullptr; size_t h_status_cap = 0;
+    bool have_host_result = false;
     // batch decode (jtk_batch_decode*)
     DevBuf dec_in_ids, dec_in_off, dec_zero, dec_tile, dec_pre, dec_out, dec_byte_off;
     DevBuf trunc_kept, trunc_flag;   // jtk_batch_truncate
@@ -75,11 +105,15 @@ struct jtk_batch {
     bool have_decode = false;
     int64_t dec_total = 0;
     JtkResult* host_result = nullptr;   // pinned
-    JtkWork work{};
+    // the last job
+    const uint8_t* job_text = nullptr;
+    const int64_t* job_doc_off = nullptr;
+    int64_t job_docs = 0, job_bytes = 0;
+    uint32_t job_flags = 0;
     bool have_result = false, synced = false;
     bool profiling = false;
-    hipEvent_t ev0[N_STAGES] = {}, ev1[N_STAGES] = {};   // start / end of each stage, on the stream it runs on
-    bool ev_ok = false, ev_recorded = false;
+    std::vector<hipEvent_t> prof_ev;     // [chunk][stage][start, end]
+    int prof_chunks = 0;                 // chunks of the last job that recorded events
 };
 
 #include "jtk_unicode_tables.h"
@@ -211,11 +245,21 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
     jtk_batch* b = new (std::nothrow) jtk_batch();
     if (!b) return fail(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
     b->enc = enc;
+    if (const char* e = getenv("JTK_CHUNK_BYTES")) { const long long v = atoll(e); if (v >= (1 << 20)) b->chunk_bytes = v; }
+    if (const char* e = getenv("JTK_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= MAX_SETS) b->n_sets = v; }
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result, sizeof(JtkResult), hipHostMallocDefault);
+    for (int k = 0; k < MAX_SETS && e == hipSuccess; k++) {
+        ChunkSet& cs = b->set[k];
+        e = hipStreamCreateWithFlags(&cs.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&cs.ev_scan, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&cs.ev_done, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
-        if (b->stream) (void)hipStreamDestroy(b->stream);
-        delete b;
+        jtk_batch_destroy(b);
         return fail(JTK_ERR_HIP, std::string("batch create: ") + hipGetErrorString(e));
     }
     *out = b;
@@ -225,93 +269,122 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
 void jtk_batch_destroy(jtk_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->enc->device);
-    (void)hipStreamSynchronize(b->stream);
-    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->zeroed, &b->piecemask, &b->plist, &b->htok, &b->docpre,
-                      &b->tile_np, &b->tile_off, &b->queues, &b->q_meta, &b->giant_cnt, &b->mid_list, &b->long_list,
-                      &b->giant_list, &b->dec_in_ids, &b->dec_in_off, &b->dec_zero,
-                      &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag,
-                      &b->tokens, &b->tok_off};
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (ChunkSet& cs : b->set) {
+        if (cs.stream) (void)hipStreamSynchronize(cs.stream);
+        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.plist, &cs.htok, &cs.docpre, &cs.tile_np, &cs.tile_off, &cs.queues, &cs.q_meta,
+                          &cs.mid_list, &cs.long_list, &cs.giant_list, &cs.giant_cnt};
+        for (DevBuf* d : bufs) d->release();
+        if (cs.ev_scan) (void)hipEventDestroy(cs.ev_scan);
+        if (cs.ev_done) (void)hipEventDestroy(cs.ev_done);
+        if (cs.stream) (void)hipStreamDestroy(cs.stream);
+    }
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->status, &b->job, &b->tokens, &b->tok_off, &b->plan, &b->dec_in_ids, &b->dec_in_off,
+                      &b->dec_zero, &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag};
     for (DevBuf* d : bufs) d->release();
-    if (b->ev_ok) { for (auto& ev : b->ev0) (void)hipEventDestroy(ev); for (auto& ev : b->ev1) (void)hipEventDestroy(ev); }
+    for (hipEvent_t ev : b->prof_ev) (void)hipEventDestroy(ev);
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
+    if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
+    if (b->h_info) (void)hipHostFree(b->h_info);
     if (b->host_result) (void)hipHostFree(b->host_result);
-    (void)hipStreamDestroy(b->stream);
+    if (b->host_plan) (void)hipHostFree(b->host_plan);
+    if (b->h_tokens) (void)hipHostFree(b->h_tokens);
+    if (b->h_tok_off) (void)hipHostFree(b->h_tok_off);
+    if (b->h_status) (void)hipHostFree(b->h_status);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
+}
+
+int jtk_batch_set_option(jtk_batch* b, int option, int64_t value) {
+    if (!b) return fail(JTK_ERR_INVALID_ARGUMENT, "batch is NULL");
+    switch (option) {
+        case JTK_OPT_CHUNK_BYTES:
+            if (value < (1 << 16)) return fail(JTK_ERR_INVALID_ARGUMENT, "chunk size must be at least 64 KiB");
+            b->chunk_bytes = value;
+            return JTK_OK;
+        case JTK_OPT_CHUNKS_IN_FLIGHT:
+            if (value < 1 || value > MAX_SETS) return fail(JTK_ERR_INVALID_ARGUMENT, "chunks in flight: 1..4");
+            b->n_sets = (int)value;
+            return JTK_OK;
+        default: return fail(JTK_ERR_INVALID_ARGUMENT, "unknown option");
+    }
 }
 
 int jtk_batch_set_profiling(jtk_batch* b, int enabled) {
     if (!b) return fail(JTK_ERR_INVALID_ARGUMENT, "batch is NULL");
-    HIP_TRY(hipSetDevice(b->enc->device));
-    if (enabled && !b->ev_ok) {
-        for (auto& ev : b->ev0) HIP_TRY(hipEventCreate(&ev));
-        for (auto& ev : b->ev1) HIP_TRY(hipEventCreate(&ev));
-        b->ev_ok = true;
-    }
     b->profiling = enabled != 0;
-    b->ev_recorded = false;
+    b->prof_chunks = 0;
     return JTK_OK;
 }
 
-int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* d_doc_off, int64_t n_docs,
-                            int64_t n_bytes, uint32_t flags, void* stream_or_null, int64_t* n_tokens) {
-    if (!b || n_docs < 0 || n_bytes < 0 || (n_bytes > 0 && !d_utf8) || !d_doc_off)
-        return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
-    if (((uintptr_t)d_utf8 & 15u) != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "device text must be 16-byte aligned");
-    if (n_bytes >= (int64_t)1 << 37) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large (128 GiB of text per call at most)");
-    const jtk_encoding* enc = b->enc;
-    HIP_TRY(hipSetDevice(enc->device));
-    hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : b->stream;
+int jtk_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(JTK_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(JTK_ERR_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return JTK_OK;
+}
+void jtk_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-    JtkWork& w = b->work;
-    w.text = d_utf8;
-    w.doc_off = d_doc_off;
+}  // extern "C"
+
+namespace {
+
+int ensure_pinned(void** p, size_t* cap, size_t bytes, size_t keep_bytes) {
+    if (bytes <= *cap) return JTK_OK;
+    void* q = nullptr;
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(JTK_ERR_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    if (*p) { if (keep_bytes) memcpy(q, *p, keep_bytes); (void)hipHostFree(*p); }
+    *p = q; *cap = want;
+    return JTK_OK;
+}
+
+// scratch of one chunk of `n_bytes` (from its tile-aligned origin) and `n_docs` documents; fills cs.work
+int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_clear) {
+    JtkWork& w = cs.work;
     w.n_bytes = n_bytes;
     w.n_docs = n_docs;
     w.n_words = (n_bytes + 1 + 63) / 64 + 2;
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
-    w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
-    w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
-
-    // zeroed per encode: docmask | status | result + list counters | queue counters
     const size_t mask_bytes = (size_t)w.n_words * 8;
-    const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
     const size_t nt = (size_t)w.n_tiles;
     const size_t qcnt_bytes = JTK_NBINS * JTK_Q_SHARDS * 4;
-    const size_t zero_bytes = mask_bytes + status_bytes + 32 + qcnt_bytes;
+    const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
     const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
     int rc;
-    if ((rc = b->zeroed.ensure(zero_bytes)) || (rc = b->piecemask.ensure(mask_bytes)) ||
-        (rc = b->plist.ensure(nt * JTK_TILE * 4)) || (rc = b->htok.ensure(nt * JTK_TILE * 4 + 64)) ||
-        (rc = b->docpre.ensure(nt * JTK_TILE * 4)) ||
-        (rc = b->tile_np.ensure(align_up(nt * 4, 16) * 2)) || (rc = b->tile_off.ensure((nt + 1) * 8)) ||
-        (rc = b->q_meta.ensure(nt * 4 * 16)) ||
-        (rc = b->queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 24)) ||
-        (rc = b->mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
-        (rc = b->long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
-        (rc = b->giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
-        (rc = b->giant_cnt.ensure(n_giant_max * 4)) ||
-        (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) ||
-        (rc = b->tok_off.ensure(((size_t)n_docs + 1) * 8)))
+    if ((rc = cs.zeroed.ensure(zero_bytes)) || (rc = cs.piecemask.ensure(mask_bytes)) ||
+        (rc = cs.plist.ensure(nt * JTK_TILE * 4)) || (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
+        (rc = cs.docpre.ensure(nt * JTK_TILE * 4)) ||
+        (rc = cs.tile_np.ensure(align_up(nt * 4, 16) * 2)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
+        (rc = cs.q_meta.ensure(nt * 4 * 16)) ||
+        (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 24)) ||
+        (rc = cs.mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
+        (rc = cs.long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
+        (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
+        (rc = cs.giant_cnt.ensure(n_giant_max * 4)))
         return rc;
-    uint8_t* z = (uint8_t*)b->zeroed.p;
+    uint8_t* z = (uint8_t*)cs.zeroed.p;
     w.docmask = (uint64_t*)z;
-    w.status = (int32_t*)(z + mask_bytes);
-    w.result = (JtkResult*)(z + mask_bytes + status_bytes);
-    w.mid_count = (uint32_t*)(z + mask_bytes + status_bytes + 16);
-    w.long_count = (uint32_t*)(z + mask_bytes + status_bytes + 20);
-    w.q_count = (uint32_t*)(z + mask_bytes + status_bytes + 32);
-    w.piecemask = (uint64_t*)b->piecemask.p;
-    w.plist = (uint32_t*)b->plist.p;
-    w.htok = (uint32_t*)b->htok.p;
-    w.docpre = (uint32_t*)b->docpre.p;
-    w.tile_np = (uint32_t*)b->tile_np.p;
-    w.tile_tot = (uint32_t*)((uint8_t*)b->tile_np.p + align_up(nt * 4, 16));
-    w.tile_off = (int64_t*)b->tile_off.p;
+    w.mid_count = (uint32_t*)(z + mask_bytes);
+    w.long_count = (uint32_t*)(z + mask_bytes + 4);
+    w.n_giant = (uint32_t*)(z + mask_bytes + 8);
+    w.q_count = (uint32_t*)(z + mask_bytes + 32);
+    w.piecemask = (uint64_t*)cs.piecemask.p;
+    w.plist = (uint32_t*)cs.plist.p;
+    w.htok = (uint32_t*)cs.htok.p;
+    w.docpre = (uint32_t*)cs.docpre.p;
+    w.tile_np = (uint32_t*)cs.tile_np.p;
+    w.tile_tot = (uint32_t*)((uint8_t*)cs.tile_np.p + align_up(nt * 4, 16));
+    w.tile_off = (int64_t*)cs.tile_off.p;
     {
         const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4};
-        uint8_t* qp = (uint8_t*)b->queues.p;                      // all the 16-byte arrays first, then the 8-byte ones
-        w.q_meta = (uint32_t*)b->q_meta.p;
+        uint8_t* qp = (uint8_t*)cs.queues.p;                      // all the 16-byte arrays first, then the 8-byte ones
+        w.q_meta = (uint32_t*)cs.q_meta.p;
         for (int k = 0; k < JTK_NBINS; k++) {
             w.qd[k] = (uint4*)qp;
             w.q_cap[k] = (int64_t)(tps * caps[k]);
@@ -322,50 +395,206 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
             qp += tps * caps[k] * JTK_Q_SHARDS * 8;
         }
     }
-    w.giant_cnt = (uint32_t*)b->giant_cnt.p;
-    w.mid_list = (JtkLongPiece*)b->mid_list.p;
-    w.long_list = (JtkLongPiece*)b->long_list.p;
-    w.giant_list = (JtkLongPiece*)b->giant_list.p;
-    w.tokens = (int32_t*)b->tokens.p;
-    w.tok_off = (int64_t*)b->tok_off.p;
+    w.giant_cnt = (uint32_t*)cs.giant_cnt.p;
+    w.mid_list = (JtkLongPiece*)cs.mid_list.p;
+    w.long_list = (JtkLongPiece*)cs.long_list.p;
+    w.giant_list = (JtkLongPiece*)cs.giant_list.p;
+    *bytes_to_clear = zero_bytes;
+    return JTK_OK;
+}
 
-    const bool prof = b->profiling && b->ev_ok;
-    int stage = 0;
-    auto begin = [&](hipStream_t st) { if (prof) (void)hipEventRecord(b->ev0[stage], st); };
-    auto end = [&](hipStream_t st) { if (prof) (void)hipEventRecord(b->ev1[stage], st); stage++; };
+// The whole job: `chunk_doc` / `chunk_off` (n_chunks + 1 entries, filled by the caller) cut the batch into runs of whole
+// documents.  Chunk c runs on scratch set c % n_sets and that set's stream; the sets' streams are forked from the main
+// stream `s` and joined into it at the end, so the job as a whole is ordered like one operation on `s`.  The only link
+// between chunks is the running token total (chunk c's scan follows chunk c - 1's).
+// h_text != NULL: the text comes from host memory, copied chunk by chunk into in_text on the chunk's stream (so the copy of
+// chunk c + 1 overlaps the kernels of chunk c).  to_host: every chunk's tokens are copied to the pinned host buffer as
+// soon as they are packed.
+int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
+            uint32_t flags, hipStream_t s, bool to_host) {
+    const jtk_encoding* enc = b->enc;
+    const int n_chunks = (int)b->chunk_doc.size() - 1;
+    const int n_sets = n_chunks < b->n_sets ? (n_chunks < 1 ? 1 : n_chunks) : b->n_sets;
+    int rc;
+    // batch-wide buffers
+    const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
+    const size_t job_bytes = 64 + ((size_t)n_chunks + 2) * 8;
+    if ((rc = b->status.ensure(status_bytes)) || (rc = b->job.ensure(job_bytes)) ||
+        (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) || (rc = b->tok_off.ensure(((size_t)n_docs + 1) * 8)))
+        return rc;
+    JtkResult* d_result = (JtkResult*)b->job.p;
+    int64_t* d_totals = (int64_t*)((uint8_t*)b->job.p + 64);       // [c]: tokens of the chunks before c
+    HIP_TRY(hipMemsetAsync(b->status.p, 0, status_bytes, s));
+    HIP_TRY(hipMemsetAsync(b->job.p, 0, job_bytes, s));
+    if (to_host) {
+        if ((rc = ensure_pinned((void**)&b->h_tok_off, &b->h_tok_off_cap, ((size_t)n_docs + 1) * 8, 0)) ||
+            (rc = ensure_pinned((void**)&b->h_status, &b->h_status_cap, (size_t)(n_docs > 0 ? n_docs : 1) * 4, 0)) ||
+            (rc = ensure_pinned((void**)&b->h_tokens, &b->h_tokens_cap, (size_t)n_bytes * 2 + 4096, 0)))     // grown as the chunks report
+            return rc;
+    }
+    const bool prof = b->profiling;
+    if (prof) {
+        const size_t need = (size_t)n_chunks * N_STAGES * 2;
+        while (b->prof_ev.size() < need) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); b->prof_ev.push_back(ev); }
+    }
+    const bool fork = n_chunks > 1 || h_text != nullptr;
+    if (fork) HIP_TRY(hipEventRecord(b->ev_fork, s));
+    for (ChunkSet& cs : b->set) cs.used = false;
 
-    begin(s);                                                   // mark_docs
-    HIP_TRY(hipMemsetAsync(b->zeroed.p, 0, zero_bytes, s));
-    jtk_launch_mark_docs(w, s);
-    end(s);
-    begin(s);                                                   // optional UTF-8 validation (the special-token check rides in pretok_split)
-    if (flags & JTK_ENCODE_VALIDATE_UTF8) jtk_launch_validate_utf8(w, s);
-    end(s);
-    begin(s);
-    jtk_launch_pretok_split(w, enc->dt, s);
-    end(s);
-    begin(s);
-    jtk_launch_piece_resolve(w, enc->dt, s);
-    end(s);
-    begin(s);
-    jtk_launch_bpe_merge(w, enc->dt, s);
-    end(s);
-    begin(s);
-    jtk_launch_tile_scan(w, s);
-    end(s);
-    begin(s);
-    jtk_launch_pack(w, s);
-    end(s);
-    begin(s);
-    jtk_launch_doc_offsets(w, s);
-    end(s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(b->host_result, w.result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
+    if ((rc = ensure_pinned((void**)&b->h_info, &b->h_info_cap, ((size_t)n_chunks + 1) * 16, 0))) return rc;
+    // tokens of chunk c to the host: on the copy stream, after the chunk's last kernel; the host needs the chunk's token
+    // range for that (written to pinned memory by its scan), so this is called one chunk behind the enqueueing
+    auto send_chunk_to_host = [&](int c) -> int {
+        ChunkSet& cs = b->set[c % n_sets];
+        HIP_TRY(hipEventSynchronize(cs.ev_scan));
+        const int64_t t0 = b->h_info[2 * c], t1 = b->h_info[2 * c + 1];
+        if (t1 > t0 && !(flags & JTK_ENCODE_COUNT_ONLY)) {
+            if ((size_t)t1 * 4 > b->h_tokens_cap) {
+                // grow: earlier chunks' copies may still be in flight into the old buffer
+                HIP_TRY(hipStreamSynchronize(b->copy_stream));
+                int rc2 = ensure_pinned((void**)&b->h_tokens, &b->h_tokens_cap, (size_t)t1 * 4 + ((size_t)n_bytes - (size_t)b->chunk_off[c + 1]) * 2, (size_t)t0 * 4);
+                if (rc2) return rc2;
+            }
+            HIP_TRY(hipStreamWaitEvent(b->copy_stream, cs.ev_done, 0));
+            HIP_TRY(hipMemcpyAsync(b->h_tokens + t0, (const int32_t*)b->tokens.p + t0, (size_t)(t1 - t0) * 4, hipMemcpyDeviceToHost, b->copy_stream));
+        }
+        return JTK_OK;
+    };
+
+    for (int c = 0; c < n_chunks; c++) {
+        ChunkSet& cs = b->set[c % n_sets];
+        hipStream_t cst = fork ? cs.stream : s;
+        const int64_t d0 = b->chunk_doc[c], d1 = b->chunk_doc[c + 1];
+        const int64_t b0 = b->chunk_off[c], b1 = b->chunk_off[c + 1];
+        const int64_t origin = b0 & ~(int64_t)(JTK_TILE - 1);
+        // (a set is reused by chunk c + n_sets on the same stream: its scratch is free by then)
+        size_t zero_bytes = 0;
+        if ((rc = prepare_set(cs, b1 - origin, d1 - d0, &zero_bytes)) != JTK_OK) return rc;
+        JtkWork& w = cs.work;
+        w.set_info = b->h_info + 2 * c;
+        w.text = d_text + origin;
+        w.text_base = origin;
+        w.lead = b0 - origin;
+        w.doc_off = d_doc_off + d0;
+        w.status = (int32_t*)b->status.p + d0;
+        w.tokens = (int32_t*)b->tokens.p;
+        w.tok_off = (int64_t*)b->tok_off.p + d0;
+        w.result = d_result;
+        w.job_tokens = d_totals + c;
+        w.job_tokens_next = d_totals + c + 1;
+        w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
+        w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
+
+        if (fork && !cs.used) { HIP_TRY(hipStreamWaitEvent(cst, b->ev_fork, 0)); cs.used = true; }
+        if (h_text && b1 > b0) {
+            // this chunk's bytes; the bytes before b0 in the first tile were copied with the previous chunk
+            HIP_TRY(hipMemcpyAsync((uint8_t*)b->in_text.p + b0, h_text + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, cst));
+        }
+        int stage = 0;
+        hipEvent_t* pe = prof ? &b->prof_ev[(size_t)c * N_STAGES * 2] : nullptr;
+        auto begin = [&]() { if (prof) (void)hipEventRecord(pe[2 * stage], cst); };
+        auto end = [&]() { if (prof) (void)hipEventRecord(pe[2 * stage + 1], cst); stage++; };
+
+        begin();                                                    // mark_docs
+        HIP_TRY(hipMemsetAsync(cs.zeroed.p, 0, zero_bytes, cst));
+        jtk_launch_mark_docs(w, cst);
+        end();
+        begin();                                                    // optional UTF-8 validation (the special-token check rides in pretok_split)
+        if (flags & JTK_ENCODE_VALIDATE_UTF8) jtk_launch_validate_utf8(w, cst);
+        end();
+        begin();
+        jtk_launch_pretok_split(w, enc->dt, cst);
+        end();
+        begin();
+        jtk_launch_piece_resolve(w, enc->dt, cst);
+        end();
+        begin();
+        jtk_launch_bpe_merge(w, enc->dt, cst);
+        end();
+        begin();
+        if (fork && c > 0) HIP_TRY(hipStreamWaitEvent(cst, b->set[(c - 1) % n_sets].ev_scan, 0));
+        jtk_launch_tile_scan(w, cst);
+        if (fork) HIP_TRY(hipEventRecord(cs.ev_scan, cst));
+        end();
+        begin();
+        jtk_launch_pack(w, cst);
+        end();
+        begin();
+        jtk_launch_doc_offsets(w, cst);
+        end();
+        HIP_TRY(hipGetLastError());
+        if (fork) HIP_TRY(hipEventRecord(cs.ev_done, cst));
+        if (to_host && c > 0) { if ((rc = send_chunk_to_host(c - 1)) != JTK_OK) return rc; }
+    }
+    if (to_host && n_chunks > 0) { if ((rc = send_chunk_to_host(n_chunks - 1)) != JTK_OK) return rc; }
+    if (fork) {
+        for (int k = 0; k < n_sets; k++)
+            if (b->set[k].used) HIP_TRY(hipStreamWaitEvent(s, b->set[k].ev_done, 0));
+        if (to_host) {
+            HIP_TRY(hipEventRecord(b->ev_copy, b->copy_stream));
+            HIP_TRY(hipStreamWaitEvent(s, b->ev_copy, 0));
+        }
+    }
+    if (to_host) {
+        HIP_TRY(hipMemcpyAsync(b->h_tok_off, b->tok_off.p, ((size_t)n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (n_docs > 0) HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipMemcpyAsync(b->host_result, d_result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
+    b->job_text = d_text;
+    b->job_doc_off = d_doc_off;
+    b->job_docs = n_docs;
+    b->job_bytes = n_bytes;
+    b->job_flags = flags;
     b->have_result = true;
+    b->have_host_result = to_host;
     b->have_trunc = false;
     b->synced = false;
     b->last_stream = s;
-    b->ev_recorded = prof;
+    b->prof_chunks = prof ? n_chunks : 0;
+    return JTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* d_doc_off, int64_t n_docs,
+                            int64_t n_bytes, uint32_t flags, void* stream_or_null, int64_t* n_tokens) {
+    if (!b || n_docs < 0 || n_bytes < 0 || (n_bytes > 0 && !d_utf8) || !d_doc_off)
+        return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (((uintptr_t)d_utf8 & 15u) != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "device text must be 16-byte aligned");
+    if (n_bytes >= (int64_t)1 << 37) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large (128 GiB of text per call at most)");
+    if (flags & JTK_ENCODE_TO_HOST) return fail(JTK_ERR_INVALID_ARGUMENT, "JTK_ENCODE_TO_HOST is for jtk_batch_encode (host buffers)");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : b->stream;
+    // chunk plan: a batch of up to one chunk needs none; a larger one reads the chunk boundaries from the offsets (the one
+    // place where this call waits for the work queued on `s` before it)
+    b->chunk_doc.assign(1, 0);
+    b->chunk_off.assign(1, 0);
+    if (n_bytes > b->chunk_bytes + b->chunk_bytes / 4 && n_docs > 1) {
+        const int nc = (int)((n_bytes + b->chunk_bytes - 1) / b->chunk_bytes);
+        int rc;
+        if ((rc = b->plan.ensure(((size_t)nc + 1) * 16))) return rc;
+        if ((rc = ensure_pinned((void**)&b->host_plan, &b->host_plan_cap, ((size_t)nc + 1) * 16, 0))) return rc;
+        int64_t* d_doc = (int64_t*)b->plan.p;
+        int64_t* d_off = d_doc + nc + 1;
+        jtk_launch_plan_chunks(d_doc_off, n_docs, b->chunk_bytes, nc, d_doc, d_off, s);
+        HIP_TRY(hipMemcpyAsync(b->host_plan, b->plan.p, ((size_t)nc + 1) * 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const int64_t* h_doc = b->host_plan;
+        const int64_t* h_off = b->host_plan + nc + 1;
+        for (int c = 1; c < nc; c++) {
+            const int64_t d = h_doc[c], o = h_off[c];
+            if (d <= b->chunk_doc.back() || d >= n_docs) continue;                 // no new document since the last boundary
+            if (o < b->chunk_off.back() || o > n_bytes) return fail(JTK_ERR_INVALID_ARGUMENT, "document offsets are not non-decreasing within [0, n_bytes]");
+            b->chunk_doc.push_back(d);
+            b->chunk_off.push_back(o);
+        }
+    }
+    b->chunk_doc.push_back(n_docs);
+    b->chunk_off.push_back(n_bytes);
+    int rc = run_job(b, d_utf8, nullptr, d_doc_off, n_docs, n_bytes, flags, s, false);
+    if (rc != JTK_OK) return rc;
     if (n_tokens) {
         HIP_TRY(hipStreamSynchronize(s));
         b->synced = true;
@@ -378,20 +607,35 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
                      uint32_t flags, int64_t* n_tokens) {
     if (!b || n_docs < 0 || !doc_off) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
     if (doc_off[0] != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off[0] must be 0");
-    for (int64_t d = 0; d < n_docs; d++)
-        if (doc_off[d + 1] < doc_off[d]) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off must be non-decreasing");
     const int64_t n_bytes = doc_off[n_docs];
     if (n_bytes > 0 && !utf8) return fail(JTK_ERR_INVALID_ARGUMENT, "utf8 is NULL");
+    if (n_bytes >= (int64_t)1 << 37) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large (128 GiB of text per call at most)");
+    // chunk plan (and the check of the offsets) in one pass
+    b->chunk_doc.assign(1, 0);
+    b->chunk_off.assign(1, 0);
+    {
+        int64_t next = b->chunk_bytes;
+        for (int64_t d = 0; d < n_docs; d++) {
+            if (doc_off[d + 1] < doc_off[d]) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off must be non-decreasing");
+            if (doc_off[d] >= next && d > b->chunk_doc.back() && n_bytes - doc_off[d] > b->chunk_bytes / 4) {
+                b->chunk_doc.push_back(d);
+                b->chunk_off.push_back(doc_off[d]);
+                next = doc_off[d] + b->chunk_bytes;
+            }
+        }
+    }
+    b->chunk_doc.push_back(n_docs);
+    b->chunk_off.push_back(n_bytes);
     HIP_TRY(hipSetDevice(b->enc->device));
     int rc;
     if ((rc = b->in_text.ensure((size_t)n_bytes + 64)) || (rc = b->in_off.ensure(((size_t)n_docs + 1) * 8))) return rc;
-    if (n_bytes > 0) HIP_TRY(hipMemcpyAsync(b->in_text.p, utf8, (size_t)n_bytes, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->in_off.p, doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
-    int64_t nt = 0;
-    rc = jtk_batch_encode_device(b, (const uint8_t*)b->in_text.p, (const int64_t*)b->in_off.p, n_docs, n_bytes, flags,
-                                 nullptr, &nt);
+    rc = run_job(b, (const uint8_t*)b->in_text.p, utf8, (const int64_t*)b->in_off.p, n_docs, n_bytes, flags & ~(uint32_t)JTK_ENCODE_TO_HOST,
+                 b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
     if (rc != JTK_OK) return rc;
-    if (n_tokens) *n_tokens = nt;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->synced = true;
+    if (n_tokens) *n_tokens = b->host_result->n_tokens;
     return JTK_OK;
 }
 
@@ -402,7 +646,7 @@ int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* 
     HIP_TRY(hipSetDevice(b->enc->device));
     if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
     if (n_tokens) *n_tokens = b->host_result->n_tokens;
-    if (n_docs) *n_docs = b->work.n_docs;
+    if (n_docs) *n_docs = b->job_docs;
     if (worst_status) *worst_status = b->host_result->worst_status;
     return JTK_OK;
 }
@@ -411,37 +655,56 @@ int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* 
     int64_t nt = 0;
     int rc = jtk_batch_result(b, &nt, nullptr, nullptr);
     if (rc != JTK_OK) return rc;
+    const bool count_only = (b->job_flags & JTK_ENCODE_COUNT_ONLY) != 0;
     if (tokens) {
-        if (b->work.count_only) return fail(JTK_ERR_INVALID_ARGUMENT, "the last encode was count-only: there are no token ids");
+        if (count_only) return fail(JTK_ERR_INVALID_ARGUMENT, "the last encode was count-only: there are no token ids");
         if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
-        if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->work.tokens, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        if (nt > 0) {
+            if (b->have_host_result) memcpy(tokens, b->h_tokens, (size_t)nt * 4);
+            else HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        }
     }
-    if (tok_off) HIP_TRY(hipMemcpy(tok_off, b->work.tok_off, ((size_t)b->work.n_docs + 1) * 8, hipMemcpyDeviceToHost));
-    if (status && b->work.n_docs > 0)
-        HIP_TRY(hipMemcpy(status, b->work.status, (size_t)b->work.n_docs * 4, hipMemcpyDeviceToHost));
+    if (tok_off) HIP_TRY(hipMemcpy(tok_off, b->tok_off.p, ((size_t)b->job_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (status && b->job_docs > 0)
+        HIP_TRY(hipMemcpy(status, b->status.p, (size_t)b->job_docs * 4, hipMemcpyDeviceToHost));
+    return JTK_OK;
+}
+
+int jtk_batch_host_result(jtk_batch* b, const int32_t** tokens, const int64_t** tok_off, const int32_t** status) {
+    if (!b || !b->have_result || !b->have_host_result)
+        return fail(JTK_ERR_INVALID_ARGUMENT, "the last encode on this batch did not run with JTK_ENCODE_TO_HOST");
+    HIP_TRY(hipSetDevice(b->enc->device));
+    if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
+    if (tokens) *tokens = (b->job_flags & JTK_ENCODE_COUNT_ONLY) ? nullptr : b->h_tokens;
+    if (tok_off) *tok_off = b->h_tok_off;
+    if (status) *status = b->h_status;
     return JTK_OK;
 }
 
 int jtk_batch_device_result(jtk_batch* b, const int32_t** d_tokens, const int64_t** d_tok_off,
                             const int32_t** d_status) {
     if (!b || !b->have_result) return fail(JTK_ERR_INVALID_ARGUMENT, "no encode has run on this batch");
-    if (d_tokens) *d_tokens = b->work.count_only ? nullptr : b->work.tokens;
-    if (d_tok_off) *d_tok_off = b->work.tok_off;
-    if (d_status) *d_status = b->work.status;
+    if (d_tokens) *d_tokens = (b->job_flags & JTK_ENCODE_COUNT_ONLY) ? nullptr : (const int32_t*)b->tokens.p;
+    if (d_tok_off) *d_tok_off = (const int64_t*)b->tok_off.p;
+    if (d_status) *d_status = (const int32_t*)b->status.p;
     return JTK_OK;
 }
 
 int jtk_batch_kernel_times(jtk_batch* b, const char** names, float* ms, int cap, int* n) {
     if (!b || !n) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
     *n = 0;
-    if (!b->ev_recorded) return fail(JTK_ERR_INVALID_ARGUMENT, "profiling was not enabled for the last encode");
+    if (b->prof_chunks <= 0) return fail(JTK_ERR_INVALID_ARGUMENT, "profiling was not enabled for the last encode");
     HIP_TRY(hipSetDevice(b->enc->device));
-    HIP_TRY(hipEventSynchronize(b->ev1[N_STAGES - 1]));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
     for (int i = 0; i < N_STAGES && i < cap; i++) {
-        float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, b->ev0[i], b->ev1[i]));
+        float sum = 0.f;
+        for (int c = 0; c < b->prof_chunks; c++) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, b->prof_ev[((size_t)c * N_STAGES + i) * 2], b->prof_ev[((size_t)c * N_STAGES + i) * 2 + 1]));
+            sum += t;
+        }
         if (names) names[i] = STAGE_NAMES[i];
-        if (ms) ms[i] = t;
+        if (ms) ms[i] = sum;
         *n = i + 1;
     }
     return JTK_OK;
@@ -452,11 +715,11 @@ int jtk_batch_truncate(jtk_batch* b, int64_t max_tokens) {
     if (!b || !b->have_result || max_tokens < 0) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments (an encode must have run on this batch)");
     HIP_TRY(hipSetDevice(b->enc->device));
     if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
-    const int64_t nd = b->work.n_docs;
+    const int64_t nd = b->job_docs;
     int rc;
     if ((rc = b->trunc_kept.ensure((size_t)(nd > 0 ? nd : 1) * 8)) || (rc = b->trunc_flag.ensure((size_t)(nd > 0 ? nd : 1)))) return rc;
     JtkTruncWork t{};
-    t.tokens = b->work.tokens; t.tok_off = b->work.tok_off; t.text = b->work.text; t.doc_off = b->work.doc_off;
+    t.tokens = (const int32_t*)b->tokens.p; t.tok_off = (const int64_t*)b->tok_off.p; t.text = b->job_text; t.doc_off = b->job_doc_off;
     t.n_docs = nd; t.tab_off = (const uint32_t*)b->enc->dec_off.p; t.max_tokens = max_tokens;
     t.kept = (int64_t*)b->trunc_kept.p; t.truncated = (uint8_t*)b->trunc_flag.p;
     jtk_launch_truncate(t, b->last_stream);
@@ -469,7 +732,7 @@ int jtk_batch_fetch_truncated(jtk_batch* b, int64_t* kept, uint8_t* truncated) {
     if (!b || !b->have_trunc) return fail(JTK_ERR_INVALID_ARGUMENT, "jtk_batch_truncate has not run on this batch");
     HIP_TRY(hipSetDevice(b->enc->device));
     HIP_TRY(hipStreamSynchronize(b->last_stream));
-    const size_t nd = (size_t)b->work.n_docs;
+    const size_t nd = (size_t)b->job_docs;
     if (kept && nd) HIP_TRY(hipMemcpy(kept, b->trunc_kept.p, nd * 8, hipMemcpyDeviceToHost));
     if (truncated && nd) HIP_TRY(hipMemcpy(truncated, b->trunc_flag.p, nd, hipMemcpyDeviceToHost));
     return JTK_OK;
@@ -592,14 +855,14 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     int rc = jtk_batch_encode(b, utf8, off, 1, flags, &nt);
     if (rc != JTK_OK) return rc;
     int32_t st = 0;
-    HIP_TRY(hipMemcpy(&st, b->work.status, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&st, b->status.p, 4, hipMemcpyDeviceToHost));
     if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
     if (st != JTK_OK) return fail(st, "document could not be encoded");
     if (max_tokens < 0) {
         if (n_tokens) *n_tokens = nt;
         if (tokens) {
             if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
-            if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->work.tokens, (size_t)nt * 4, hipMemcpyDeviceToHost));
+            if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
         }
         return JTK_OK;
     }
@@ -607,7 +870,7 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     // GptBytePairEncoding.java:90-100 is the first min(maxTokens, total) tokens of the full result.
     int64_t keep = nt < max_tokens ? nt : max_tokens;
     std::vector<int32_t> head((size_t)(keep > 0 ? keep : 1));
-    if (keep > 0) HIP_TRY(hipMemcpy(head.data(), b->work.tokens, (size_t)keep * 4, hipMemcpyDeviceToHost));
+    if (keep > 0) HIP_TRY(hipMemcpy(head.data(), b->tokens.p, (size_t)keep * 4, hipMemcpyDeviceToHost));
     std::vector<int64_t> cum((size_t)keep + 1, 0);
     for (int64_t k = 0; k < keep; k++) cum[(size_t)k + 1] = cum[(size_t)k] + b->enc->tok_len[(size_t)head[(size_t)k]];
     const int64_t text16 = utf16_len(utf8, len);

@@ -74,17 +74,23 @@ struct JtkLongPiece {
     int64_t len;
 };
 
-struct JtkResult {
+struct JtkResult {          // of a whole batch (all its chunks)
     int64_t n_tokens;
     int32_t worst_status;
-    uint32_t n_giant;       // pieces longer than JTK_LONG_CAP (listed by piece_resolve, merged by the last phase of k_bpe_merge_all)
+    uint32_t pad;
 };
 
-// Device-side working set of one encode call (all pointers into the batch's scratch).
+// Device-side working set of ONE CHUNK of an encode call: a run of whole documents of the batch, encoded with one scratch
+// set.  A batch is one chunk, or several that flow through a few scratch sets on their own streams (jtk_abi.cpp).
+// Positions are relative to the chunk's origin `text` = batch text + text_base (text_base is a multiple of JTK_TILE, so the
+// chunk's first document starts `lead` < JTK_TILE bytes in; the bytes before it belong to the previous chunk and start no
+// piece here).  doc_off / status / tok_off point at the chunk's first document in the batch-wide arrays.
 struct JtkWork {
     const uint8_t* text;
-    const int64_t* doc_off;
-    int64_t n_bytes;
+    const int64_t* doc_off; // [n_docs + 1] positions in the whole batch (subtract text_base)
+    int64_t text_base;
+    int64_t lead;
+    int64_t n_bytes;        // from the chunk's origin to the end of its last document
     int64_t n_docs;
     int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
     int64_t n_tiles;
@@ -113,9 +119,13 @@ struct JtkWork {
     uint32_t* giant_cnt;    // token count per giant_list entry
     uint32_t* mid_count;
     uint32_t* long_count;
+    uint32_t* n_giant;      // pieces longer than JTK_LONG_CAP (listed by piece_resolve, merged by the last phase of k_bpe_merge_all)
     int32_t* status;        // per document
-    int32_t* tokens;        // output, packed
+    int32_t* tokens;        // output of the whole batch, packed (tile_off already includes the earlier chunks' tokens)
     int64_t* tok_off;       // output, n_docs + 1
+    const int64_t* job_tokens;   // tokens of the batch's earlier chunks (written by the previous chunk's scan)
+    int64_t* job_tokens_next;    // ... including this one (for the next chunk)
+    int64_t* set_info;      // [2] (device-visible host memory) first token of this chunk, end of its last
     JtkResult* result;
 };
 
@@ -153,6 +163,9 @@ void jtk_launch_truncate(const JtkTruncWork& w, hipStream_t s);
 void jtk_launch_decode_count(const JtkDecodeWork& w, hipStream_t s);     // mark, count, scan
 void jtk_launch_decode_scatter(const JtkDecodeWork& w, hipStream_t s);   // scatter, offsets
 
+// chunk plan of a batch whose offsets are in device memory: out_doc[c], out_off[c] for c = 0..n_chunks
+void jtk_launch_plan_chunks(const int64_t* doc_off, int64_t n_docs, int64_t chunk_bytes, int n_chunks, int64_t* out_doc, int64_t* out_off,
+                            hipStream_t s);
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);

@@ -66,16 +66,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 __global__ void __launch_bounds__(256) k_mark_docs(JtkWork w) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > w.n_docs) return;
-    const int64_t q = w.doc_off[d];
+    const int64_t q = w.doc_off[d] - w.text_base;                // position in this chunk
     // the offsets are caller memory: out-of-range or decreasing ones are reported (JTK_ERR_INVALID_ARGUMENT as the
     // batch's worst status), never followed
-    const bool bad = q < 0 || q > w.n_bytes || (d > 0 && w.doc_off[d - 1] > q) || (d == 0 && q != 0) || (d == w.n_docs && q != w.n_bytes);
+    const bool bad = q < w.lead || q > w.n_bytes || (d > 0 && w.doc_off[d - 1] - w.text_base > q) || (d == 0 && q != w.lead) ||
+                     (d == w.n_docs && q != w.n_bytes);
     if (bad) { atomicMin(&w.result->worst_status, -1 /* JTK_ERR_INVALID_ARGUMENT */); return; }
     atomicOr((unsigned long long*)&w.docmask[q >> 6], 1ull << (q & 63));
 }
 
 // index of the document containing byte position p (skipping empty documents)
-__device__ int64_t find_doc(const int64_t* doc_off, int64_t n_docs, int64_t p) {
+__device__ int64_t find_doc(const JtkWork& w, int64_t p) {
+    const int64_t* doc_off = w.doc_off;
+    const int64_t n_docs = w.n_docs;
+    p += w.text_base;                            // doc_off holds positions in the whole batch
     int64_t lo = 0, hi = n_docs;                 // first d with doc_off[d] > p
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -96,8 +100,8 @@ __device__ void special_check_at(const JtkWork& w, const JtkDeviceTables& t, int
         bool eq = true;
         for (int j = 0; j < len && eq; j++) eq = (w.text[p + j] == t.special[s][j]);
         if (!eq) continue;
-        const int64_t d = find_doc(w.doc_off, w.n_docs, p);
-        if (d >= 0 && p + len <= w.doc_off[d + 1]) atomicMin(&w.status[d], -2 /* JTK_ERR_UNSUPPORTED_SPECIAL */);
+        const int64_t d = find_doc(w, p);
+        if (d >= 0 && p + len <= w.doc_off[d + 1] - w.text_base) atomicMin(&w.status[d], -2 /* JTK_ERR_UNSUPPORTED_SPECIAL */);
     }
 }
 
@@ -143,7 +147,7 @@ __global__ void __launch_bounds__(256) k_validate_utf8(JtkWork w) {
         }
     }
     if (bad) {
-        const int64_t d = find_doc(w.doc_off, w.n_docs, p);
+        const int64_t d = find_doc(w, p);
         if (d >= 0) atomicMin(&w.status[d], -6 /* JTK_ERR_BAD_UTF8 */);
     }
 }
@@ -395,6 +399,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         // only positions before n start pieces: the end sentinel (bit n) does not, and the padding words after it are
         // not written by pretok_split for every n (they may hold bits of an earlier, longer batch)
         if (wd * 64 + 63 >= n) m &= (wd * 64 >= n) ? 0ull : ((1ull << (n - wd * 64)) - 1ull);
+        // a chunk of a larger batch starts at its first document, not at its first (tile-aligned) byte
+        if (wd * 64 < w.lead) m &= (wd * 64 + 64 <= w.lead) ? 0ull : ~((1ull << (w.lead - wd * 64)) - 1ull);
         s_pm[tid] = m;
     }
     if (tid < JTK_NBINS) s_qn[tid] = 0;
@@ -504,11 +510,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 // giant piece (a run of one byte value, mostly): merged by a whole workgroup in the last phase of
                 // k_bpe_merge_all; its token count goes to giant_cnt, the htok header only says so
                 if (len64 <= JTK_GIANT_CAP) {
-                    const uint32_t gi = atomicAdd(&w.result->n_giant, 1u);
+                    const uint32_t gi = atomicAdd(w.n_giant, 1u);
                     w.giant_list[gi] = JtkLongPiece{B + s, len64};
                     w.giant_cnt[gi] = 0;
                 } else {
-                    const int64_t d = find_doc(w.doc_off, w.n_docs, B + s);
+                    const int64_t d = find_doc(w, B + s);
                     if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
                 }
                 w.htok[B + s] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;         // count: giant_cnt, or none at all
@@ -1376,7 +1382,7 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     }
     if (tid == JTK_NBINS) s_count[JTK_NBINS] = *w.mid_count;
     if (tid == JTK_NBINS + 1) s_count[JTK_NBINS + 1] = *w.long_count;
-    if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = w.result->n_giant;
+    if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = *w.n_giant;
     __syncthreads();
     // ordinary text has no piece above 16 bytes in most workgroups' shards: nothing to stage, nothing to do
     if (!(s_count[1] | s_count[2] | s_count[3] | s_count[4] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2])) return;
@@ -1441,14 +1447,18 @@ __global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
     const uint32_t inc = wave_incl_scan(sum);
     if (lane == 63) s_wsum[wv] = inc;
     __syncthreads();
-    uint64_t before = 0;
+    const uint64_t job_before = (uint64_t)*w.job_tokens;      // tokens of the batch's earlier chunks (their scans ran before this one)
+    uint64_t before = job_before;
     for (int k = 0; k < 16; k++) before += s_part[k];
     for (int k = 0; k < wv; k++) before += s_wsum[k];
     uint64_t run = before + inc - sum;
     for (int j = 0; j < 4; j++) { if (i0 + j < w.n_tiles) w.tile_off[i0 + j] = (int64_t)run; run += v[j]; }
     if (chunk == gridDim.x - 1 && tid == 1023) {           // lanes past the last tile carry the grand total
         w.tile_off[w.n_tiles] = (int64_t)run;
+        w.set_info[0] = (int64_t)job_before;               // this chunk's first token
+        w.set_info[1] = (int64_t)run;                      // ... and the end of its last
         w.result->n_tokens = (int64_t)run;
+        *w.job_tokens_next = (int64_t)run;
     }
 }
 
@@ -1461,7 +1471,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
 __device__ __forceinline__ uint32_t hard_count(const JtkWork& w, int64_t pos) {
     const uint32_t c = (w.htok[pos] >> JTK_HT_CNT_SHIFT) & JTK_HT_CNT_MASK;
     if (c != JTK_HT_ESCAPE) return c;
-    const uint32_t ng = w.result->n_giant;                  // giant piece: look its count up (rare)
+    const uint32_t ng = *w.n_giant;                         // giant piece: look its count up (rare)
     for (uint32_t i = 0; i < ng; i++)
         if (w.giant_list[i].start == pos) return w.giant_cnt[i];
     return 0;                                               // longer than JTK_GIANT_CAP: no tokens, status set
@@ -1615,9 +1625,10 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
 __global__ void __launch_bounds__(256) k_doc_offsets(JtkWork w) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > w.n_docs) return;
-    const int64_t q = w.doc_off[d];
+    const int64_t q = w.doc_off[d] - w.text_base;
     // a document starts a piece; documents at the very end (empty ones, and the end offset) start after the last token
-    w.tok_off[d] = (q >= w.n_bytes) ? w.tile_off[w.n_tiles] : w.tile_off[q / T] + w.docpre[q];
+    // (offsets that k_mark_docs rejected are not followed)
+    w.tok_off[d] = (q >= w.n_bytes || q < w.lead) ? w.tile_off[w.n_tiles] : w.tile_off[q / T] + w.docpre[q];
     if (d < w.n_docs) {
         const int32_t st = w.status[d];
         if (st < 0) atomicMin(&w.result->worst_status, st);
@@ -1625,6 +1636,30 @@ __global__ void __launch_bounds__(256) k_doc_offsets(JtkWork w) {
 }
 
 }  // namespace
+
+// chunk c of a large batch starts at the first document at or after byte c * chunk_bytes
+__global__ void __launch_bounds__(256) k_plan_chunks(const int64_t* doc_off, int64_t n_docs, int64_t chunk_bytes, int n_chunks,
+                                                     int64_t* out_doc, int64_t* out_off) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c > n_chunks) return;
+    int64_t lo = 0, hi = n_docs;                              // first d with doc_off[d] >= c * chunk_bytes
+    if (c == n_chunks) lo = n_docs;
+    else {
+        const int64_t target = (int64_t)c * chunk_bytes;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (doc_off[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+    }
+    out_doc[c] = lo;
+    out_off[c] = doc_off[lo];
+}
+
+void jtk_launch_plan_chunks(const int64_t* doc_off, int64_t n_docs, int64_t chunk_bytes, int n_chunks, int64_t* out_doc, int64_t* out_off,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(k_plan_chunks, dim3((unsigned)((n_chunks + 1 + 255) / 256)), dim3(256), 0, s, doc_off, n_docs, chunk_bytes, n_chunks,
+                       out_doc, out_off);
+}
 
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s) {
     const int64_t n = w.n_docs + 1;

@@ -71,6 +71,24 @@ class BatchResult:
         return len(self.tok_off) - 1
 
 
+class HostBuffer:
+    """Page-locked host memory (jtk_host_alloc) as a numpy array: input buffers the device reads by DMA."""
+
+    def __init__(self, n_bytes):
+        p = C.c_void_p()
+        _check(N.lib().jtk_host_alloc(int(n_bytes), C.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(n_bytes), 1),))[:int(n_bytes)]
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            N.lib().jtk_host_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+
 class Batch:
     """One caller thread's stream + device scratch (jtk_batch)."""
 
@@ -87,16 +105,36 @@ class Batch:
 
     __del__ = close
 
-    def encode_host(self, text_u8, doc_off, ordinary=False, validate=False, count_only=False):
+    def set_option(self, option, value):
+        """jtk_batch_set_option: N.JTK_OPT_CHUNK_BYTES, N.JTK_OPT_CHUNKS_IN_FLIGHT."""
+        _check(N.lib().jtk_batch_set_option(self._h, int(option), int(value)))
+
+    def encode_host(self, text_u8, doc_off, ordinary=False, validate=False, count_only=False, to_host=False):
+        """Host buffers in (numpy arrays, or anything with .ctypes.data such as a pinned HostBuffer view).  to_host: the result
+        is streamed to the batch's pinned host memory while later chunks are encoded (read it with host_result())."""
         text_u8 = np.ascontiguousarray(text_u8, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
         nt = C.c_int64(0)
         flags = ((N.JTK_ENCODE_ORDINARY if ordinary else 0) | (N.JTK_ENCODE_VALIDATE_UTF8 if validate else 0)
-                 | (N.JTK_ENCODE_COUNT_ONLY if count_only else 0))
+                 | (N.JTK_ENCODE_COUNT_ONLY if count_only else 0) | (N.JTK_ENCODE_TO_HOST if to_host else 0))
         self._count_only = count_only
         _check(N.lib().jtk_batch_encode(self._h, text_u8.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1,
                                         flags, C.byref(nt)))
         return nt.value
+
+    def host_result(self):
+        """After encode_host(to_host=True): zero-copy numpy views of the batch's pinned result buffers (valid until the
+        next encode on this batch)."""
+        nt, nd, _ = self.result()
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(N.lib().jtk_batch_host_result(self._h, C.byref(a), C.byref(b), C.byref(c)))
+
+        def view(ptr, n, ctype, dtype):
+            if not ptr or n == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
+        tokens = view(a.value, nt, C.c_int32, np.int32)
+        return BatchResult(tokens, view(b.value, nd + 1, C.c_int64, np.int64), view(c.value, nd, C.c_int32, np.int32))
 
     def encode_device(self, d_text_ptr, d_doc_off_ptr, n_docs, n_bytes, ordinary=False, stream=None, sync=True):
         nt = C.c_int64(0)

@@ -601,3 +601,61 @@ def test_create_destroy_loop_does_not_leak(jt):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over 8 create/destroy rounds" % (free0 - free1)
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_chunked_batches_equal_oracle(jt, in_flight):
+    """A batch larger than one chunk is cut into runs of whole documents that flow through the batch's scratch sets on their own
+    streams (device and host entry points, results on the device or streamed to pinned host memory).  With a tiny chunk size a
+    small corpus makes dozens of chunks: ragged documents, empty documents at chunk boundaries, documents larger than a chunk,
+    special-token status, every encoding's split pattern -- all bit-exact vs the oracle."""
+    import torch
+    from jtokkit_amd import corpus, _native as N
+    dev = torch.device("cuda:0")
+    for name, (text, doc_off) in (("cl100k_base", corpus.mixed(700, seed=31)), ("r50k_base", corpus.english(4000, seed=32))):
+        enc = jt.get_encoding(name)
+        o = oracle_lib.get(name)
+        # extra documents: empty ones, one much larger than a chunk, one with a special-token literal
+        docs = [text[doc_off[d]:doc_off[d + 1]].tobytes() for d in range(len(doc_off) - 1)]
+        big = b" ".join(docs[:300])[:700000]
+        while big and (big[-1] & 0xC0) == 0x80:
+            big = big[:-1]
+        if big and big[-1] >= 0xC0:
+            big = big[:-1]
+        docs = docs[:100] + [b"", b""] + [big] + [b""] + docs[100:400] + [b"x <|endoftext|> y"] + docs[400:]
+        text2 = np.frombuffer(b"".join(docs), dtype=np.uint8).copy()
+        off2 = np.zeros(len(docs) + 1, dtype=np.int64)
+        np.cumsum([len(d) for d in docs], out=off2[1:])
+        exp_tok, exp_off = o.encode_batch(text2, off2, threads=8)
+        sp = docs.index(b"x <|endoftext|> y")
+        b = enc.new_batch()
+        b.set_option(N.JTK_OPT_CHUNK_BYTES, 64 * 1024)
+        b.set_option(N.JTK_OPT_CHUNKS_IN_FLIGHT, in_flight)
+        # device entry point
+        d_text, d_off = torch.from_numpy(text2).to(dev), torch.from_numpy(off2).to(dev)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(docs), len(text2), ordinary=False, sync=(rep == 0))
+            res = b.fetch()
+            assert np.array_equal(res.tok_off, exp_off) and np.array_equal(res.tokens, exp_tok), (name, "device", rep)
+            assert res.status[sp] == -2 and (np.delete(res.status, sp) == 0).all()
+            assert b.result()[2] == -2
+        # host entry point, result on the device
+        b.encode_host(text2, off2, ordinary=True)
+        res = b.fetch()
+        assert np.array_equal(res.tok_off, exp_off) and np.array_equal(res.tokens, exp_tok), (name, "host")
+        assert (res.status == 0).all()
+        # host entry point from pinned memory, result streamed to pinned host memory
+        hb = jt.HostBuffer(len(text2))
+        hb.array[:] = text2
+        nt = b.encode_host(hb.array, off2, ordinary=True, to_host=True)
+        res = b.host_result()
+        assert nt == len(exp_tok) and np.array_equal(res.tok_off, exp_off) and np.array_equal(res.tokens, exp_tok), (name, "to_host")
+        assert (res.status == 0).all()
+        # maxTokens for the whole (chunked) batch
+        kept, flag = b.truncate(7)
+        for d in (0, 50, 102, 103, len(docs) - 1):
+            e, tr = o.encode_ordinary(docs[d], 7)
+            assert res.tokens[res.tok_off[d]:res.tok_off[d] + kept[d]].tolist() == e and bool(flag[d]) == tr, (name, d)
+        hb.close()
+        b.close()
