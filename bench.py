@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- input MB/s of the cl100k_base batch encode path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the whole hot path (mark_docs, pretok_split, piece_resolve, bpe_merge, pack -- every
-kernel of jtk_batch_encode_device) over one batch of synthetic documents that is already resident in
-HBM, ending with the total token count on the host; for N > 1 ranks each step also all-gathers the
-per-shard token totals over RCCL and stitches the shard's token offsets into global ones.
+One "step" = one pass of the whole hot path over one batch of synthetic documents that is already resident in HBM: ONE
+jtk_batch_encode_device call (inside it the batch is cut into chunks of whole documents that flow through the library's
+scratch sets on their own streams: mark_docs, pretok_split, piece_resolve, bpe_merge, tile_scan, pack, doc_offsets per
+chunk), ending with every document's token ids and offsets in HBM.
 
-N = 1 workload: BASELINE.json configs[1] -- cl100k_base, 100k synthetic English docs (~1 KB each).
-N > 1: weak scaling, every rank encodes its own 100k-doc shard (own seed); value = all ranks' input
-bytes / max-over-ranks time.  Launch: `python bench.py` or
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+N = 1 (default): BASELINE.json configs[2] -- cl100k_base, 1M mixed UTF-8 docs (emoji + CJK, ~4 KB each, ~4.1 GB), the largest
+single-GPU configuration -- is the headline; the same JSON line carries sub-records for configs[1] (100k English docs),
+configs[4] (r50k_base + p50k_base back to back on the 1M-doc corpus), one shard of configs[3] (1.25M English docs), an
+end-to-end figure (host buffers in, token ids on the host) and a vocabulary-stress corpus.
+N > 1: configs[3] -- 10M English docs (~10 GB) in contiguous document shards, one per rank (strong scaling: the corpus is
+fixed, 10M / N docs per GPU), one RCCL all-gather of the per-shard token totals per step for the offset stitch.
+Launch: `python bench.py` or `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+SHARD_DOCS = {"mixed": 25000, "english": 100000}     # documents per generator call (one seed each)
 
 
 class _DevArray:
@@ -32,13 +37,96 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16, ordinary=False):
-    """Oracle (CPU restatement of GptBytePairEncoding.encode, kind "port") on the host cores, on a
-    bounded prefix of the same workload: one task per document on a fixed pool, as the reference's JMH
-    harness does (AbstractMultiThreadedBenchmark.java:35-45)."""
+# ---- corpora ------------------------------------------------------------------------------------------------------
+def _gen_shard(job):
+    kind, n_docs, seed = job
+    from jtokkit_amd import corpus
+    text, doc_off = (corpus.mixed if kind == "mixed" else corpus.english)(n_docs, seed=seed)
+    return text, doc_off
+
+
+def make_corpus(kind, n_docs, seed0, workers):
+    """n_docs documents of corpus.mixed / corpus.english, generated in shards of SHARD_DOCS[kind] documents (shard i: seed
+    seed0 + i) by a process pool and concatenated in shard order."""
+    per = SHARD_DOCS[kind]
+    jobs = []
+    left, i = n_docs, 0
+    while left > 0:
+        jobs.append((kind, min(per, left), seed0 + i))
+        left -= per
+        i += 1
+    if len(jobs) == 1 or workers <= 1:
+        parts = [_gen_shard(j) for j in jobs]
+    else:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.map(_gen_shard, jobs, chunksize=1)
+    total = sum(len(t) for t, _ in parts)
+    text = np.empty(total, dtype=np.uint8)
+    doc_off = np.empty(n_docs + 1, dtype=np.int64)
+    doc_off[0] = 0
+    pos, d = 0, 0
+    for t, off in parts:
+        text[pos:pos + len(t)] = t
+        doc_off[d + 1:d + len(off)] = off[1:] + pos
+        pos += len(t)
+        d += len(off) - 1
+    return text, doc_off
+
+
+def vocab_stress_corpus(n_docs, mean_tokens=256, seed=10):
+    """Documents made by decoding uniformly random cl100k_base token ids (every rank-table entry equally likely, ~100k
+    distinct 'words'): the whole-piece and pair tables are hit all over, not in a small hot set.  Invalid UTF-8 is fine for
+    encodeOrdinary on bytes (the oracle and the device treat the bytes alike); ids whose bytes are not valid UTF-8 on their
+    own are kept only if the concatenation decodes -- simplest: keep ASCII/valid-UTF-8 entries only."""
+    import base64
+    path = os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken")
+    toks = []
+    for line in open(path, "rb"):
+        a, _ = line.split()
+        t = base64.b64decode(a)
+        try:
+            t.decode("utf-8")
+        except UnicodeDecodeError:
+            continue
+        toks.append(t)
+    lens = np.array([len(t) for t in toks], dtype=np.int64)
+    offs = np.zeros(len(toks) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    flat = np.frombuffer(b"".join(toks), dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+    n_tok = n_docs * mean_tokens
+    ids = rng.integers(0, len(toks), n_tok)
+    l = lens[ids]
+    ends = np.cumsum(l)
+    total = int(ends[-1])
+    idx = np.arange(total, dtype=np.int64)
+    idx -= np.repeat(ends - l, l)
+    idx += np.repeat(offs[ids], l)
+    text = flat[idx]
+    doc_off = np.concatenate([[0], ends[mean_tokens - 1::mean_tokens]]).astype(np.int64)
+    return np.ascontiguousarray(text), doc_off
+
+
+# ---- CPU baseline ---------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(encoding, text, doc_off, max_threads=16, ordinary=False, budget_s=20.0):
+    """The oracle (CPU restatement of GptBytePairEncoding.encode, kind "port") on the host cores, the way the reference's JMH
+    harness measures (AbstractMultiThreadedBenchmark.java:35-45: every document one task on a fixed pool, wall time for the
+    whole corpus; benchmark/build.gradle.kts:20-25: 1 warm-up + 5 measured single-shot iterations), on a bounded prefix of the
+    same workload, at 1 thread and at all allotted cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    enc = oracle_lib.get("cl100k_base")
+    enc = oracle_lib.get(encoding)
     # the GPU box allots 16 host cores per GPU (the machine itself shows far more)
     cores = min(len(os.sched_getaffinity(0)), max_threads)
     n_docs = len(doc_off) - 1
@@ -48,43 +136,135 @@ def cpu_baseline(text, doc_off, budget_s=12.0, max_threads=16, ordinary=False):
         enc.encode_batch(text, doc_off[:nd + 1], threads=threads, ordinary=ordinary, want_tokens=False)
         return time.perf_counter() - t0
 
-    probe = min(n_docs, 400)
-    run(probe, cores)                                   # warm-up (page in the table)
-    dt = run(probe, cores)
-    rate = doc_off[probe] / dt
-    nd = int(min(n_docs, max(probe, np.searchsorted(doc_off, rate * budget_s))))
-    dt = run(nd, cores)
-    one = min(nd, max(probe, nd // cores))
-    dt1 = run(one, 1)
+    probe = min(n_docs, 200)
+    run(probe, cores)                                   # page in the table
+    rate = doc_off[probe] / run(probe, cores)
+    per_pass = budget_s / 2 / 6                         # 6 passes per thread count, half the budget each
+    nd_all = int(min(n_docs, max(probe, np.searchsorted(doc_off, rate * per_pass))))
+    nd_one = int(min(n_docs, max(probe, np.searchsorted(doc_off, rate / cores * per_pass))))
+
+    def measure(nd, threads):
+        run(nd, threads)                                # 1 warm-up iteration
+        ts = sorted(run(nd, threads) for _ in range(5)) # 5 measured iterations
+        return doc_off[nd] / 1e6 / ts[2], doc_off[nd] / 1e6 / ts[0], doc_off[nd] / 1e6 / ts[4]
+    med_all, best_all, worst_all = measure(nd_all, cores)
+    med_one, _, _ = measure(nd_one, 1)
     return {
-        "value": round(doc_off[nd] / 1e6 / dt, 2), "unit": "MB/s", "cores": cores, "kind": "port",
-        "sample": "first %d docs (%.1f MB) of the same corpus, %d threads, one task per doc; "
-                  "1 thread on %d docs: %.2f MB/s" % (nd, doc_off[nd] / 1e6, cores, one, doc_off[one] / 1e6 / dt1),
+        "value": round(med_all, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model(), "one_thread_MBps": round(med_one, 2),
+        "method": "1 warm-up + 5 timed passes, median (range %.1f-%.1f MB/s); one task per document on a fixed pool" % (worst_all, best_all),
+        "sample": "first %d docs (%.1f MB) of the headline corpus on %d threads; first %d docs (%.1f MB) on 1 thread" % (
+            nd_all, doc_off[nd_all] / 1e6, cores, nd_one, doc_off[nd_one] / 1e6),
     }
 
 
-# stage (HIP-event bracket in jtk_batch_kernel_times) -> the kernel it launches, as rocprofv3 names it
-STAGE_KERNEL = {"bpe_merge": "k_bpe_merge_all", "piece_resolve": "k_piece_resolve", "pretok_split": "k_pretok_split<1>",
-                "pack": "k_pack_tokens", "doc_offsets": "k_doc_offsets"}
+# ---- timing helpers ---------------------------------------------------------------------------------------------------
+STAGE_KERNEL = {"bpe_merge": "k_bpe_merge", "piece_resolve": "k_piece_resolve", "pretok_split": "k_pretok_split<1>",
+                "pack": "k_pack_tokens", "doc_offsets": "k_doc_offsets", "tile_scan": "k_tile_scan"}
+
+
+def time_encode(torch, batches, d_text, d_off, n_docs, n_bytes, steps, warmup, ordinary, world=1, dist=None, after_step=None):
+    """`warmup` untimed steps, then `steps` timed ones bracketed by barrier + synchronize.  Steps rotate over `batches` (each
+    has its own streams and scratch) without waiting for one another; everything has finished when the clock stops.
+    Returns (seconds, per-stage ms summed over the chunks of a step, averaged over steps, tokens)."""
+    streams = [torch.cuda.ExternalStream(b.stream()) for b in batches]
+    acc = {}
+    nb = len(batches)
+
+    def run(k, collect):
+        pending = []
+        for i in range(k):
+            b, st = batches[i % nb], streams[i % nb]
+            b.encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=ordinary, sync=False)
+            if after_step is not None:
+                with torch.cuda.stream(st):
+                    after_step(b)
+            pending.append(b)
+            if len(pending) == nb:                              # the oldest step's events: waits for that step only
+                bb = pending.pop(0)
+                if collect:
+                    for name, v in bb.kernel_times().items():
+                        acc[name] = acc.get(name, 0.0) + v
+        for bb in pending:
+            if collect:
+                for name, v in bb.kernel_times().items():
+                    acc[name] = acc.get(name, 0.0) + v
+
+    torch.cuda.synchronize()
+    run(warmup, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nt = batches[0].result()[0]
+    return dt, {k: v / steps for k, v in acc.items()}, nt
+
+
+def verify_sample(enc_name, batch, text, doc_off, n_sample, ordinary, seed=0):
+    """After the clock: a seeded document sample of the batch's last result against the CPU oracle, bit-exact."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    o = oracle_lib.get(enc_name)
+    n_docs = len(doc_off) - 1
+    res = batch.fetch()
+    assert int(res.tok_off[-1]) == len(res.tokens) and (np.diff(res.tok_off) >= 0).all()
+    bad = np.nonzero(res.status != 0)[0]
+    if len(bad):
+        raise SystemExit("bench: document %d has status %d" % (int(bad[0]), int(res.status[bad[0]])))
+    rng = np.random.default_rng(seed)
+    sample = np.sort(rng.choice(n_docs, min(n_docs, n_sample), replace=False))
+    lens = doc_off[sample + 1] - doc_off[sample]
+    s_off = np.zeros(len(sample) + 1, dtype=np.int64)
+    np.cumsum(lens, out=s_off[1:])
+    idx = np.arange(int(s_off[-1]), dtype=np.int64)
+    idx -= np.repeat(s_off[:-1], lens)
+    idx += np.repeat(doc_off[sample], lens)
+    s_text = text[idx]
+    exp_tok, exp_off = o.encode_batch(s_text, s_off, threads=min(16, len(os.sched_getaffinity(0))), ordinary=True)
+    for k, d in enumerate(sample):
+        got = res.tokens[res.tok_off[d]:res.tok_off[d + 1]]
+        if not np.array_equal(got, exp_tok[exp_off[k]:exp_off[k + 1]]):
+            raise SystemExit("bench: document %d differs from the oracle" % int(d))
+    return len(sample)
+
+
+def traffic_for(workload_key, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this workload (profiles/pmc_traffic.json), collected
+    and corrected as MI355X_MICROARCH.md prescribes (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 on gfx950)."""
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        k = pt["workloads"][workload_key]["kernels"][kernel]
+        return int((k["hbm_read_MB"] + k["hbm_write_MB"]) * 1e6), pt.get("build", "?")
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--docs-per-gpu", type=int, default=100000)
-    ap.add_argument("--workload", choices=["english", "mixed"], default="english")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "vocab"], default=None,
+                    help="headline workload (default: cfg3 at N = 1, cfg4 at N > 1)")
+    ap.add_argument("--docs", type=int, default=None, help="documents in the headline corpus (default: the config's stated size)")
     ap.add_argument("--encoding", default="cl100k_base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--ordinary", action="store_true",
                     help="time encodeOrdinary() instead of encode() (skips the special-token check of GptBytePairEncoding.java:52-56)")
     ap.add_argument("--no-verify", action="store_true", help="skip the after-the-clock check of a document sample against the oracle")
-    ap.add_argument("--serial-pass", action="store_true",
-                    help="after the timed region, 5 more steps strictly one after the other: per-kernel times without overlap")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight, each on its own HIP stream with its own scratch (1 = strictly one after the other)")
+    ap.add_argument("--no-subrecords", action="store_true", help="headline only")
+    ap.add_argument("--chunk-mb", type=int, default=None, help="JTK_OPT_CHUNK_BYTES in MiB (library default: 1024)")
+    ap.add_argument("--in-flight", type=int, default=None, help="JTK_OPT_CHUNKS_IN_FLIGHT (library default: 2)")
+    ap.add_argument("--serial", action="store_true", help="one chunk at a time (clean per-kernel times, no overlap)")
+    ap.add_argument("--gen-workers", type=int, default=None)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,82 +283,68 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     import jtokkit_amd
-    from jtokkit_amd import corpus, sharding
+    from jtokkit_amd import _native as N, sharding
+    workers = args.gen_workers or max(1, min(16, len(os.sched_getaffinity(0))) // max(1, min(world, 8 if not rehearsal else world)))
 
-    # ---- workload: this rank's shard, resident in HBM ----------------------------------------------
-    if args.workload == "english":
-        text, doc_off = corpus.english(args.docs_per_gpu, seed=2 + rank)
-        wl = "cl100k_base, %dk synthetic English docs (~1 KB each) per GPU" % (args.docs_per_gpu // 1000)
+    def new_batch(enc):
+        b = enc.new_batch()
+        if args.chunk_mb:
+            b.set_option(N.JTK_OPT_CHUNK_BYTES, args.chunk_mb << 20)
+        if args.serial:
+            b.set_option(N.JTK_OPT_CHUNKS_IN_FLIGHT, 1)
+        elif args.in_flight:
+            b.set_option(N.JTK_OPT_CHUNKS_IN_FLIGHT, args.in_flight)
+        b.set_profiling(True)
+        return b
+
+    # ---- headline workload: this rank's documents, resident in HBM ----------------------------------------------------
+    wl_name = args.workload or ("cfg3" if world == 1 else "cfg4")
+    if wl_name == "cfg3":
+        total_docs = args.docs or 1000000
+        text, doc_off = make_corpus("mixed", total_docs, 3, workers)
+        wl = "%s, %s mixed UTF-8 docs (emoji + CJK, ~4 KB each)" % (args.encoding, "1M" if total_docs == 1000000 else str(total_docs))
+        wl_key, scaling = "cfg3", "weak"
+    elif wl_name == "cfg2":
+        total_docs = args.docs or 100000
+        text, doc_off = make_corpus("english", total_docs, 2, workers)
+        wl = "%s, %dk synthetic English docs (~1 KB each)" % (args.encoding, total_docs // 1000)
+        wl_key, scaling = "cfg2", "weak"
+    elif wl_name == "vocab":
+        total_docs = args.docs or 100000
+        text, doc_off = vocab_stress_corpus(total_docs)
+        wl = "%s, %dk vocabulary-stress docs (uniformly random rank-table entries)" % (args.encoding, total_docs // 1000)
+        wl_key, scaling = "vocab", "weak"
     else:
-        text, doc_off = corpus.mixed(args.docs_per_gpu, seed=3 + rank)
-        wl = "%s, %dk mixed UTF-8 docs (emoji + CJK, ~4 KB each) per GPU" % (args.encoding, args.docs_per_gpu // 1000)
-    if args.encoding != "cl100k_base":
-        wl = wl.replace("cl100k_base", args.encoding)
+        total_docs = args.docs or 10000000
+        # contiguous document ranges of the 10M-doc corpus (corpus shards of 100k docs, seed 4 + shard index), one per rank
+        n_shards = (total_docs + SHARD_DOCS["english"] - 1) // SHARD_DOCS["english"]
+        s0, s1 = rank * n_shards // world, (rank + 1) * n_shards // world
+        my_docs = min(total_docs, s1 * SHARD_DOCS["english"]) - s0 * SHARD_DOCS["english"]
+        text, doc_off = make_corpus("english", my_docs, 4 + s0, workers)
+        wl = "%s, %s English docs (~1 KB each) sharded over %d GPU(s) by contiguous document ranges" % (
+            args.encoding, "10M" if total_docs == 10000000 else str(total_docs), world)
+        wl_key, scaling = "cfg2", "strong"
     n_docs, n_bytes = len(doc_off) - 1, int(doc_off[-1])
     d_text = torch.from_numpy(text).to(dev)
     d_off = torch.from_numpy(doc_off).to(dev)
     enc = jtokkit_amd.get_encoding(args.encoding, device=local_rank)
-    # `inflight` batches, each with its own HIP stream and scratch: the kernels of step i + 1 fill the CUs that step i's
-    # tail leaves idle (every step still does all of its work; all of them have finished when the clock stops).
-    # Nothing in a step waits for the host.
-    n_fl = max(1, args.inflight)
-    batches = [enc.new_batch() for _ in range(n_fl)]
-    streams = [torch.cuda.ExternalStream(b.stream(), device=dev) for b in batches]     # the batches' own streams, seen by torch
-    for b in batches:
-        b.set_profiling(True)
+    batch = new_batch(enc)
 
-    def step(i):
-        b, st = batches[i % n_fl], streams[i % n_fl]
-        with torch.cuda.stream(st):
-            b.encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=args.ordinary, stream=st.cuda_stream, sync=False)
-            if world > 1:
-                # shard token totals -> every rank; exclusive prefix = this shard's global token offset (same stream)
-                _, off_ptr, _ = b.device_result()
-                g_off = torch.as_tensor(_DevArray(off_ptr, n_docs + 1, "<i8"), device=dev)
-                _, base = sharding.gather_shard_totals(g_off[-1:])
-                sharding.stitch_offsets(g_off, base)
-        return b
-
-    def run(k, acc):
-        pending = []
-        for i in range(k):
-            pending.append(step(i))
-            if len(pending) == n_fl:                          # the oldest step's events: waits for that step only
-                b = pending.pop(0)
-                if acc is not None:
-                    for name, v in b.kernel_times().items():
-                        acc[name] = acc.get(name, 0.0) + v
-        for b in pending:
-            if acc is not None:
-                for name, v in b.kernel_times().items():
-                    acc[name] = acc.get(name, 0.0) + v
-
-    torch.cuda.synchronize()
-    run(args.warmup, None)
-    stage_ms = {}
-    torch.cuda.synchronize()
+    after = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps, stage_ms)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    nt = batches[0].result()[0]
+        def after(b):
+            # shard token totals -> every rank; exclusive prefix = this shard's global token offset (same stream as the encode)
+            _, off_ptr, _ = b.device_result()
+            g_off = torch.as_tensor(_DevArray(off_ptr, n_docs + 1, "<i8"), device=dev)
+            _, base = sharding.gather_shard_totals(g_off[-1:])
+            if getattr(b, "_global_off", None) is None:
+                b._global_off = torch.empty_like(g_off)
+            torch.add(g_off, base, out=b._global_off)           # the stitch: global offsets of this shard's documents
 
-    # --serial-pass, after the clock: a few steps strictly one after the other, for per-kernel times without overlap
-    serial_ms = {}
-    if n_fl > 1 and args.serial_pass:
-        for _ in range(5):
-            batches[0].encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=args.ordinary,
-                                     stream=streams[0].cuda_stream, sync=True)
-            for name, v in batches[0].kernel_times().items():
-                serial_ms[name] = serial_ms.get(name, 0.0) + v / 5
+    dt, stage_ms, nt = time_encode(torch, [batch], d_text, d_off, n_docs, n_bytes, args.steps, args.warmup, args.ordinary,
+                                   world, dist, after)
 
-    # max over ranks, sum of bytes
+    # max over ranks, sums of bytes
     stats = torch.tensor([dt, float(n_bytes), float(nt), float(n_docs)], dtype=torch.float64,
                          device=torch.device("cpu") if rehearsal else dev)
     if world > 1:
@@ -190,72 +356,194 @@ def main():
     t_max = float(allst[:, 0].max())
     total_bytes = float(allst[:, 1].sum())
 
+    # after the clock: this rank's result against the oracle (1 % of the documents, at most 10,000)
+    verified = None
+    if not args.no_verify:
+        ns = verify_sample(args.encoding, batch, text, doc_off, min(10000, max(500, n_docs // 100)), args.ordinary)
+        verified = "%d sampled documents per rank == CPU oracle, bit-exact; offsets monotone; all status 0" % ns
+        if world > 1:
+            ok = torch.tensor([1.0], device=torch.device("cpu") if rehearsal else dev)
+            dist.all_reduce(ok)
+            assert int(ok.item()) == world
+
+    out = None
     if rank == 0:
         steps = args.steps
-        for k in stage_ms:
-            stage_ms[k] /= steps
-        dom = max((k for k in stage_ms if k in STAGE_KERNEL), key=stage_ms.get)     # stages that are exactly one kernel
-        dom_kernel = STAGE_KERNEL.get(dom, dom)
-        # HBM bytes of one launch of that kernel from the committed PMC passes (same workload only)
-        traffic = None
-        try:
-            pt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-            if pt.get("workload") == wl and dom_kernel in pt["kernels"]:
-                k = pt["kernels"][dom_kernel]
-                traffic = int((k["hbm_read_MB"] + k["hbm_write_MB"]) * 1e6)
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        dom = max((k for k in stage_ms if k in STAGE_KERNEL), key=stage_ms.get)     # stages that are one kernel (bpe_merge: its lean kernel dominates)
+        dom_kernel = STAGE_KERNEL[dom]
         # algorithmic bytes of one batch: input once + int32 tokens once + both offset arrays
         bytes_alg = n_bytes + 4 * nt + 16 * (n_docs + 1)
-        achieved = bytes_alg / (stage_ms[dom] * 1e-3) / 1e9
+        n_launch = max(1, len(batch_chunks(batch, n_bytes, args)))
+        avg_launch_ms = stage_ms[dom] / n_launch
+        achieved = bytes_alg / n_launch / (avg_launch_ms * 1e-3) / 1e9
+        traffic, traffic_build = traffic_for(wl_key, dom_kernel)
         out = {
-            "metric": "input MB/s encoded (cl100k_base), bit-exact vs CPU oracle",
+            "metric": "input MB/s encoded (cl100k_base), HBM-resident input and output, bit-exact vs CPU oracle",
             "value": round(total_bytes * steps / t_max / 1e6, 1),
             "unit": "MB/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(t_max / steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": wl, "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes, "tokens_per_gpu": int(nt),
-                       "sharding": "contiguous doc shards, one per GPU" + ("; RCCL all-gather of shard token totals" if world > 1 else ""),
-                       "batches_in_flight": n_fl},
+            "config": {"workload": wl, "docs": int(allst[:, 3].sum()), "bytes": int(total_bytes), "tokens": int(allst[:, 2].sum()),
+                       "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes,
+                       "encode": "encodeOrdinary()" if args.ordinary else "encode() incl. the special-token check",
+                       "chunking": "%d chunks of whole documents per step (~%d MiB each), %s in flight on their own streams" % (
+                           n_launch, (args.chunk_mb or 1024), "1" if args.serial else str(args.in_flight or 2)),
+                       "sharding": ("contiguous document ranges, one per GPU; RCCL all-gather of the shard token totals per step"
+                                    if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_alg),
-                         "avg_launch_ms": round(stage_ms[dom], 4)},
+                         "traffic_source": ("profiles/pmc_traffic.json [%s], build %s, per launch (one chunk)" % (wl_key, traffic_build)) if traffic else None,
+                         "algorithmic_bytes_per_launch": int(bytes_alg / n_launch),
+                         "avg_launch_ms": round(avg_launch_ms, 4), "launches_per_step": n_launch,
+                         "whole_step_frac": round(bytes_alg / (t_max / steps) / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "kernel_ms_serial": {k: round(v, 4) for k, v in serial_ms.items()} or None,
+            "verified": verified,
         }
-        if serial_ms:
-            # the same kernel alone on the GPU (steps one after the other, after the timed region): its duration without
-            # the time-sharing that batches in flight bring
-            a = bytes_alg / (serial_ms[dom] * 1e-3) / 1e9
-            out["roofline_serial"] = {"kernel": dom_kernel, "achieved": round(a, 2), "frac": round(a / HBM_PEAK_GBS, 5),
-                                      "avg_launch_ms": round(serial_ms[dom], 4)}
-        if world == 1 and not args.no_verify:
-            # after the clock (N = 1; with N > 1 the shard's offsets are global): the last result of every batch in flight, a document sample against the CPU oracle
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib
-            o = oracle_lib.get(args.encoding)
-            rng = np.random.default_rng(0)
-            sample = rng.choice(n_docs, min(n_docs, 500), replace=False)
-            for b in batches[:min(n_fl, args.steps + args.warmup)]:
-                res = b.fetch()
-                assert (res.status == 0).all() and int(res.tok_off[-1]) == len(res.tokens) == nt
-                for d in sample:
-                    doc = text[doc_off[d]:doc_off[d + 1]].tobytes()
-                    exp = o.encode(doc) if not args.ordinary else o.encode_ordinary(doc)
-                    if res.doc(int(d)).tolist() != exp:
-                        raise SystemExit("bench: document %d differs from the oracle" % int(d))
-            out["verified"] = "%d sampled documents of each of the %d batches in flight == CPU oracle" % (len(sample), n_fl)
+    if world == 1 and not args.no_subrecords:
+        sub = {}
+        subrecords(sub, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, d_text, d_off, workers, wl_name)
+        out.update(sub)
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(text, doc_off, max_threads=args.cpu_threads, ordinary=args.ordinary)
+            out["cpu_baseline"] = cpu_baseline(args.encoding, text, doc_off, max_threads=args.cpu_threads, ordinary=args.ordinary)
         print(json.dumps(out), flush=True)
-    for b in batches:
-        b.close()
+    batch.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def batch_chunks(batch, n_bytes, args):
+    """The chunk count the library used for a batch of n_bytes (same rule as jtk_batch_encode_device)."""
+    cb = (args.chunk_mb or 1024) << 20
+    if n_bytes <= cb + cb // 4:
+        return [0]
+    return list(range((n_bytes + cb - 1) // cb))
+
+
+def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, d_text, d_off, workers, wl_name):
+    """N = 1: the other BASELINE.json configs and the measurements next to the headline, each checked against the oracle
+    after its clock."""
+    n_docs, n_bytes = len(doc_off) - 1, int(doc_off[-1])
+    enc = jtokkit_amd.get_encoding("cl100k_base", device=0)
+
+    def rate(nb, dt, steps):
+        return round(nb * steps / dt / 1e6, 1)
+
+    # ---- configs[1]: 100k English docs, HBM-resident; one batch alone and two batches in flight (round 1's headline mode)
+    if wl_name != "cfg2":
+        t2, o2 = make_corpus("english", 100000, 2, workers)
+        d_t2, d_o2 = torch.from_numpy(t2).to(dev), torch.from_numpy(o2).to(dev)
+        b1, b2 = new_batch(enc), new_batch(enc)
+        dt1, st1, nt2 = time_encode(torch, [b1], d_t2, d_o2, len(o2) - 1, len(t2), 20, 3, args.ordinary)
+        ns = None if args.no_verify else verify_sample("cl100k_base", b1, t2, o2, 1000, args.ordinary)
+        dt2, _, _ = time_encode(torch, [b1, b2], d_t2, d_o2, len(o2) - 1, len(t2), 20, 4, args.ordinary)
+        alg = len(t2) + 4 * nt2 + 16 * len(o2)
+        dom = max((k for k in st1 if k in STAGE_KERNEL), key=st1.get)
+        n_launch = len(batch_chunks(b1, len(t2), args))
+        out["cfg2"] = {"workload": "cl100k_base, 100k synthetic English docs (~1 KB each), 1xMI355X", "bytes": len(t2), "tokens": int(nt2),
+                       "value": rate(len(t2), dt1, 20), "unit": "MB/s", "ms_per_step": round(dt1 / 20 * 1e3, 4),
+                       "two_batches_in_flight": {"value": rate(len(t2), dt2, 20), "ms_per_step": round(dt2 / 20 * 1e3, 4)},
+                       "kernel_ms": {k: round(v, 4) for k, v in st1.items()},
+                       "roofline": {"kernel": STAGE_KERNEL[dom], "achieved": round(alg / (st1[dom] * 1e-3) / 1e9, 2),
+                                    "frac": round(alg / (st1[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "traffic": traffic_for("cfg2", STAGE_KERNEL[dom])[0], "launches_per_step": n_launch,
+                                    "whole_step_frac": round(alg / (dt1 / 20) / 1e9 / HBM_PEAK_GBS, 5)},
+                       "verified": None if ns is None else "%d sampled documents == CPU oracle" % ns}
+        # ---- end to end: host buffers in (pinned), token ids on the host (pinned), PCIe both ways inside the clock
+        hb = jtokkit_amd.HostBuffer(len(t2))
+        hb.array[:] = t2
+        be = new_batch(enc)
+        be.set_option(jtokkit_amd._native.JTK_OPT_HOST_CHUNK_BYTES, 16 << 20)
+        be.set_option(jtokkit_amd._native.JTK_OPT_CHUNKS_IN_FLIGHT, 3)
+        for _ in range(2):
+            be.encode_host(hb.array, o2, ordinary=args.ordinary, to_host=True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            be.encode_host(hb.array, o2, ordinary=args.ordinary, to_host=True)
+        dte = (time.perf_counter() - t0) / 5
+        res = be.host_result()
+        if not args.no_verify:
+            r1 = b1.fetch()
+            assert np.array_equal(res.tokens, r1.tokens) and np.array_equal(res.tok_off, r1.tok_off)
+        for _ in range(1):
+            be.encode_host(t2, o2, ordinary=args.ordinary)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            be.encode_host(t2, o2, ordinary=args.ordinary)
+            be.fetch()
+        dtp = (time.perf_counter() - t0) / 3
+        out["end_to_end"] = {"workload": "configs[1] corpus: host buffers in -> token ids, offsets and status in host memory, every step",
+                             "pinned": {"value": round(len(t2) / dte / 1e6, 1), "unit": "MB/s of input", "ms_per_step": round(dte * 1e3, 3),
+                                        "path": "jtk_host_alloc input, JTK_ENCODE_TO_HOST (16 MiB chunks, 3 in flight: H2D, kernels and D2H overlap), result read in place",
+                                        "bytes_over_pcie": int(len(t2) + 4 * nt2 + 20 * len(o2))},
+                             "pageable": {"value": round(len(t2) / dtp / 1e6, 1), "unit": "MB/s of input", "ms_per_step": round(dtp * 1e3, 3),
+                                          "path": "numpy arrays in, jtk_batch_encode + jtk_batch_fetch into numpy arrays"},
+                             "verified": None if args.no_verify else "identical to the HBM-resident result"}
+        hb.close()
+        for b in (b1, b2, be):
+            b.close()
+        del d_t2, d_o2
+
+    # ---- configs[4]: r50k_base then p50k_base back to back on the 1M-doc corpus (rank-table swap)
+    if wl_name == "cfg3":
+        encs = {n: jtokkit_amd.get_encoding(n, device=0) for n in ("r50k_base", "p50k_base")}
+        bs = {n: new_batch(e) for n, e in encs.items()}
+        alone = {}
+        for n in encs:
+            dt_n, _, nt_n = time_encode(torch, [bs[n]], d_text, d_off, n_docs, n_bytes, 2, 1, args.ordinary)
+            alone[n] = (dt_n / 2, nt_n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            for n in ("r50k_base", "p50k_base"):
+                bs[n].encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, ordinary=args.ordinary, sync=False)
+                bs[n].result()                                   # strictly back to back: the next table's pass starts after this one's end
+        torch.cuda.synchronize()
+        dt_bb = (time.perf_counter() - t0) / reps
+        ver = None
+        if not args.no_verify:
+            ver = {n: verify_sample(n, bs[n], text, doc_off, 2000, args.ordinary, seed=5) for n in encs}
+        out["cfg5"] = {"workload": "r50k_base + p50k_base back to back on the 1M-doc mixed corpus (two passes, one per rank table)",
+                       "value": round(2 * n_bytes / dt_bb / 1e6, 1), "unit": "MB/s (bytes of both passes / time of both)",
+                       "ms_per_pair": round(dt_bb * 1e3, 3),
+                       "alone_ms": {n: round(v[0] * 1e3, 3) for n, v in alone.items()}, "tokens": {n: int(v[1]) for n, v in alone.items()},
+                       "swap_ms": round((dt_bb - sum(v[0] for v in alone.values())) * 1e3, 3),
+                       "swap": "both encodings' device tables stay resident (a few MB each); switching is passing another table pointer to "
+                               "the same kernels, so the swap cost is the back-to-back pair minus the two passes alone (cold L2 for the new tables)",
+                       "verified": None if ver is None else "%d sampled documents per encoding == CPU oracle" % min(ver.values())}
+        for b in bs.values():
+            b.close()
+
+    # ---- one shard of configs[3] on one GPU: the N = 1 point of the 10M-doc strong-scaling curve (1.25M English docs)
+    if wl_name == "cfg3":
+        t4, o4 = make_corpus("english", 1250000, 4, workers)
+        d_t4, d_o4 = torch.from_numpy(t4).to(dev), torch.from_numpy(o4).to(dev)
+        b4 = new_batch(enc)
+        dt4, _, nt4 = time_encode(torch, [b4], d_t4, d_o4, len(o4) - 1, len(t4), 3, 1, args.ordinary)
+        ns = None if args.no_verify else verify_sample("cl100k_base", b4, t4, o4, 5000, args.ordinary, seed=7)
+        out["cfg4_shard"] = {"workload": "one 8-GPU shard of configs[3]: 1.25M English docs (~1 KB each) on 1xMI355X",
+                             "bytes": len(t4), "tokens": int(nt4), "value": rate(len(t4), dt4, 3), "unit": "MB/s",
+                             "ms_per_step": round(dt4 / 3 * 1e3, 3),
+                             "verified": None if ns is None else "%d sampled documents == CPU oracle" % ns}
+        b4.close()
+        del d_t4, d_o4, t4, o4
+
+    # ---- vocabulary stress: documents of uniformly random rank-table entries (the lookups miss the caches realistically)
+    if wl_name != "vocab":
+        tv, ov = vocab_stress_corpus(100000)
+        d_tv, d_ov = torch.from_numpy(tv).to(dev), torch.from_numpy(ov).to(dev)
+        bv = new_batch(enc)
+        dtv, stv, ntv = time_encode(torch, [bv], d_tv, d_ov, len(ov) - 1, len(tv), 10, 2, True)
+        ns = None if args.no_verify else verify_sample("cl100k_base", bv, tv, ov, 500, True, seed=9)
+        out["vocab_stress"] = {"workload": "100k docs of 256 uniformly random cl100k_base rank-table entries each (~100k distinct words)",
+                               "bytes": len(tv), "tokens": int(ntv), "value": rate(len(tv), dtv, 10), "unit": "MB/s",
+                               "ms_per_step": round(dtv / 10 * 1e3, 4), "kernel_ms": {k: round(v, 4) for k, v in stv.items()},
+                               "verified": None if ns is None else "%d sampled documents == CPU oracle" % ns}
+        bv.close()
 
 
 if __name__ == "__main__":

@@ -65,8 +65,12 @@ enum {
  * through a few scratch sets, each on its own HIP stream: the copies and kernels of consecutive chunks overlap, and the
  * device scratch is sized by the chunk, not by the batch. */
 enum {
-    JTK_OPT_CHUNK_BYTES = 1,      /* target bytes of text per chunk (default 64 MiB; env JTK_CHUNK_BYTES) */
-    JTK_OPT_CHUNKS_IN_FLIGHT = 2  /* scratch sets / streams, 1..4 (default 2; env JTK_CHUNKS_IN_FLIGHT) */
+    JTK_OPT_CHUNK_BYTES = 1,      /* target bytes of text per chunk, device-resident input (default 1 GiB: large chunks
+                                     have fewer launches and kernel tails; env JTK_CHUNK_BYTES).  Scratch: ~30 bytes per
+                                     byte of chunk per set */
+    JTK_OPT_CHUNKS_IN_FLIGHT = 2, /* scratch sets / streams, 1..4 (default 2; env JTK_CHUNKS_IN_FLIGHT) */
+    JTK_OPT_HOST_CHUNK_BYTES = 3  /* ... host input (default 32 MiB: the copy of one chunk overlaps the kernels of another;
+                                     env JTK_HOST_CHUNK_BYTES) */
 };
 
 typedef struct jtk_encoding jtk_encoding;

@@ -30,6 +30,7 @@ JTK_ENCODE_COUNT_ONLY = 4
 JTK_ENCODE_TO_HOST = 8
 JTK_OPT_CHUNK_BYTES = 1
 JTK_OPT_CHUNKS_IN_FLIGHT = 2
+JTK_OPT_HOST_CHUNK_BYTES = 3
 
 # every symbol include/jtokkit_amd.h declares: (restype, argtypes)
 _p = C.c_void_p

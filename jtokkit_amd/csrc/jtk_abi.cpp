@@ -83,7 +83,8 @@ struct jtk_batch {
     size_t h_info_cap = 0;
     ChunkSet set[MAX_SETS];
     int n_sets = 2;                      // chunks in flight (JTK_OPT_CHUNKS_IN_FLIGHT)
-    int64_t chunk_bytes = (int64_t)64 << 20;   // JTK_OPT_CHUNK_BYTES
+    int64_t chunk_bytes = (int64_t)1 << 30;    // JTK_OPT_CHUNK_BYTES: device-resident input (large chunks: fewer launches and kernel tails)
+    int64_t host_chunk_bytes = (int64_t)32 << 20;   // JTK_OPT_HOST_CHUNK_BYTES: host input (small chunks: copies overlap kernels)
     // the whole batch
     DevBuf in_text, in_off;          // device copy of host input (host-buffer entry point)
     DevBuf status, job;              // per document | JtkResult + running token totals per chunk
@@ -246,6 +247,7 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
     if (!b) return fail(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
     b->enc = enc;
     if (const char* e = getenv("JTK_CHUNK_BYTES")) { const long long v = atoll(e); if (v >= (1 << 20)) b->chunk_bytes = v; }
+    if (const char* e = getenv("JTK_HOST_CHUNK_BYTES")) { const long long v = atoll(e); if (v >= (1 << 16)) b->host_chunk_bytes = v; }
     if (const char* e = getenv("JTK_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= MAX_SETS) b->n_sets = v; }
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking);
@@ -302,6 +304,10 @@ int jtk_batch_set_option(jtk_batch* b, int option, int64_t value) {
         case JTK_OPT_CHUNK_BYTES:
             if (value < (1 << 16)) return fail(JTK_ERR_INVALID_ARGUMENT, "chunk size must be at least 64 KiB");
             b->chunk_bytes = value;
+            return JTK_OK;
+        case JTK_OPT_HOST_CHUNK_BYTES:
+            if (value < (1 << 16)) return fail(JTK_ERR_INVALID_ARGUMENT, "chunk size must be at least 64 KiB");
+            b->host_chunk_bytes = value;
             return JTK_OK;
         case JTK_OPT_CHUNKS_IN_FLIGHT:
             if (value < 1 || value > MAX_SETS) return fail(JTK_ERR_INVALID_ARGUMENT, "chunks in flight: 1..4");
@@ -611,16 +617,17 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
     if (n_bytes > 0 && !utf8) return fail(JTK_ERR_INVALID_ARGUMENT, "utf8 is NULL");
     if (n_bytes >= (int64_t)1 << 37) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large (128 GiB of text per call at most)");
     // chunk plan (and the check of the offsets) in one pass
+    const int64_t cb = b->host_chunk_bytes < b->chunk_bytes ? b->host_chunk_bytes : b->chunk_bytes;
     b->chunk_doc.assign(1, 0);
     b->chunk_off.assign(1, 0);
     {
-        int64_t next = b->chunk_bytes;
+        int64_t next = cb;
         for (int64_t d = 0; d < n_docs; d++) {
             if (doc_off[d + 1] < doc_off[d]) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off must be non-decreasing");
-            if (doc_off[d] >= next && d > b->chunk_doc.back() && n_bytes - doc_off[d] > b->chunk_bytes / 4) {
+            if (doc_off[d] >= next && d > b->chunk_doc.back() && n_bytes - doc_off[d] > cb / 4) {
                 b->chunk_doc.push_back(d);
                 b->chunk_off.push_back(doc_off[d]);
-                next = doc_off[d] + b->chunk_bytes;
+                next = doc_off[d] + cb;
             }
         }
     }

@@ -6,7 +6,7 @@
 // pretok_split    k_pretok_split    GptBytePairEncoding.java:77-80 matcher.find()/group() with EncodingFactory.java:63,105;
 //                                   for encode(): the special-token check :52-56 (text.contains(specialToken))
 // piece_resolve   k_piece_resolve   :81-83 whole-piece shortcut (TokenEncoder lookups) + queueing of the other pieces
-// bpe_merge       k_bpe_merge_all   :84-86 + bytePairMerge :200-275 + getRank :285-300   (last phase: giant pieces > 8 KiB)
+// bpe_merge       k_bpe_merge       :84-86 + bytePairMerge :200-275 + getRank :285-300   (last phase: giant pieces > 8 KiB)
 // pack            k_tile_scan, k_pack_tokens, k_doc_offsets   out.add / addAll (:82,:117):
 //                                   the document-order token stream and per-document offsets
 //
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             else if (len64 <= JTK_LONG_CAP) w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
             else {
                 // giant piece (a run of one byte value, mostly): merged by a whole workgroup in the last phase of
-                // k_bpe_merge_all; its token count goes to giant_cnt, the htok header only says so
+                // k_bpe_merge; its token count goes to giant_cnt, the htok header only says so
                 if (len64 <= JTK_GIANT_CAP) {
                     const uint32_t gi = atomicAdd(w.n_giant, 1u);
                     w.giant_list[gi] = JtkLongPiece{B + s, len64};
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_bpe_merge_lean: bytePairMerge (GptBytePairEncoding.java:200-275) of the queued pieces of <= 64 bytes -- all
+// lean bins of k_bpe_merge: bytePairMerge (GptBytePairEncoding.java:200-275) of the queued pieces of <= 64 bytes -- all
 // but a handful of the pieces that need merging -- ONE LANE PER PIECE, no state machine: a wave takes 64 consecutive
 // queue entries, expands them (byte -> id and the 2-byte-token ranks from LDS tables), then all lanes step together:
 // leftmost minimum over the pair keys (:234-240), the two neighbour lookups in the (left id, right id) pair table,
@@ -838,30 +838,6 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
             }
         }
     }
-}
-
-__global__ void __launch_bounds__(ML_THREADS) k_bpe_merge_lean(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint32_t s_id[16384];
-    __shared__ uint32_t s_rk[16384];
-    __shared__ uint64_t s_bpbits[1024];
-    __shared__ uint32_t s_bpranks[JTK_BP_MAX];
-    __shared__ uint16_t s_bpcum[1024];
-    __shared__ uint32_t s_brank[256];
-    const int tid = threadIdx.x;
-    const int shard = blockIdx.x % JTK_Q_SHARDS;
-    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS;
-    const uint32_t n0 = w.q_count[0 * JTK_Q_SHARDS + shard], n1 = w.q_count[1 * JTK_Q_SHARDS + shard], n2 = w.q_count[2 * JTK_Q_SHARDS + shard];
-    const bool w0 = kq * (uint32_t)ML_THREADS < n0, w1 = kq * (uint32_t)(ML_THREADS / 2) < n1, w2 = kq * (uint32_t)(ML_THREADS / 4) < n2;
-    if (!(w0 || w1 || w2)) return;
-    s_bpbits[tid] = t.bp.bits[tid];
-    s_bpcum[tid] = t.bp.cum[tid];
-    for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
-    if (tid < 256) s_brank[tid] = t.byte_rank[tid];
-    __syncthreads();
-    const LeanLds L{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
-    if (w0) lean_bin<16, ML_THREADS, 0>(w, t, L, n0);
-    if (w1) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 1>(w, t, L, n1); }
-    if (w2) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 2>(w, t, L, n2); }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1240,7 +1216,7 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
 
 // ---------------------------------------------------------------------------------------------------
 // merge_giant: pieces of 8 KiB .. 1 MiB (a run of one byte value, mostly).  One workgroup per piece, the last
-// phase of k_bpe_merge_all.  Parts live in the scratch words of the piece's own byte positions -- ids in
+// phase of k_bpe_merge.  Parts live in the scratch words of the piece's own byte positions -- ids in
 // htok[start ..], pair ranks in docpre[start ..] (pack writes docpre only later) -- so nothing is sized or
 // launched by the host and the whole encode stays asynchronous.  A chunk-minimum cache in LDS (one packed key
 // per 256 positions) keeps a merge at O(#chunks / threads + 256) instead of O(len).  Rare; exact; far cheaper
@@ -1361,12 +1337,13 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_bpe_merge_all: ONE persistent launch for all of bytePairMerge (except the giant pieces): the five length bins
-// one after the other, then the wave-per-piece lists.  All phases share the 128 KiB of LDS parts and the staged
-// tables; a workgroup barrier separates them (their LDS layouts differ), but there is no device-wide barrier and
-// no launch gap between them, and on ordinary text the later phases find empty queues and cost nothing.
+// k_bpe_merge: ONE persistent launch for all of bytePairMerge: the lean bins (pieces of <= 64 bytes: all but a handful),
+// then the state-machine bins for pieces of up to 256 bytes, the wave-per-piece lists (<= 512, <= 8192 bytes) and the
+// workgroup-per-piece giants.  All phases share the 128 KiB of LDS parts and the staged tables; a workgroup barrier
+// separates them (their LDS layouts differ), but there is no device-wide barrier and no launch gap between them, and
+// on ordinary text the later phases find empty queues and cost nothing.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTables t) {
+__global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
     __shared__ uint32_t s_id[16384];
     __shared__ uint32_t s_rk[16384];
     __shared__ uint64_t s_bpbits[1024];
@@ -1376,22 +1353,32 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
     __shared__ uint32_t s_next[JTK_NBINS];
     __shared__ uint32_t s_count[JTK_NBINS + 3];
     const int tid = threadIdx.x;
+    const int shard = blockIdx.x % JTK_Q_SHARDS;
+    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS;
     if (tid < JTK_NBINS) {
         s_next[tid] = 0;
-        s_count[tid] = tid <= 2 ? 0u : w.q_count[tid * JTK_Q_SHARDS + blockIdx.x % JTK_Q_SHARDS];   // bins 0..2: k_bpe_merge_lean
+        s_count[tid] = w.q_count[tid * JTK_Q_SHARDS + shard];
     }
     if (tid == JTK_NBINS) s_count[JTK_NBINS] = *w.mid_count;
     if (tid == JTK_NBINS + 1) s_count[JTK_NBINS + 1] = *w.long_count;
     if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = *w.n_giant;
     __syncthreads();
-    // ordinary text has no piece above 16 bytes in most workgroups' shards: nothing to stage, nothing to do
-    if (!(s_count[1] | s_count[2] | s_count[3] | s_count[4] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2])) return;
-    for (int i = tid; i < 1024; i += 1024) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
-    for (int i = tid; i < JTK_BP_MAX; i += 1024) s_bpranks[i] = t.bp.ranks[i];
-    for (int i = tid; i < 256; i += 1024) s_brank[i] = t.byte_rank[i];
-    __syncthreads();
-    const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
     // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
+    const uint32_t n0 = s_count[0], n1 = s_count[1], n2 = s_count[2];
+    const bool w0 = kq * (uint32_t)ML_THREADS < n0, w1 = kq * (uint32_t)(ML_THREADS / 2) < n1, w2 = kq * (uint32_t)(ML_THREADS / 4) < n2;
+    const bool rest = (s_count[3] | s_count[4] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
+    if (!(w0 || w1 || w2 || rest)) return;
+    s_bpbits[tid] = t.bp.bits[tid];
+    s_bpcum[tid] = t.bp.cum[tid];
+    for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
+    if (tid < 256) s_brank[tid] = t.byte_rank[tid];
+    __syncthreads();
+    const LeanLds LL{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
+    if (w0) lean_bin<16, ML_THREADS, 0>(w, t, LL, n0);
+    if (w1) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 1>(w, t, LL, n1); }
+    if (w2) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 2>(w, t, LL, n2); }
+    if (!rest) return;
+    const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
     if (s_count[3]) { __syncthreads(); merge_bin<128, 128, 3>(w, t, L); }
     if (s_count[4]) { __syncthreads(); merge_bin<256, 64, 4>(w, t, L); }
     // pieces of 257..512 bytes: every wave of the grid takes pieces, parts in its own 2 x 512 words
@@ -1400,7 +1387,7 @@ __global__ void __launch_bounds__(1024) k_bpe_merge_all(JtkWork w, JtkDeviceTabl
         __syncthreads();
         merge_long<JTK_MID_CAP>(w, t, s_id + wv * JTK_MID_CAP, s_rk + wv * JTK_MID_CAP, blockIdx.x * 16u + wv, gridDim.x * 16u);
     }
-    // pieces of 513..8192 bytes (and the listing of longer ones): one wave per workgroup, parts in 2 x 8192 words
+    // pieces of 513..8192 bytes: one wave per workgroup, parts in 2 x 8192 words
     if (s_count[JTK_NBINS + 1]) {
         __syncthreads();
         if (wv == 0) merge_long<JTK_LONG_CAP>(w, t, s_id, s_rk, blockIdx.x, gridDim.x);
@@ -1678,8 +1665,7 @@ void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStr
     hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    hipLaunchKernelGGL(k_bpe_merge_lean, dim3(JTK_Q_SHARDS * ML_WGS_PER_SHARD), dim3(ML_THREADS), 0, s, w, t);
-    hipLaunchKernelGGL(k_bpe_merge_all, dim3(JTK_Q_SHARDS * JTK_M_WGS_PER_SHARD), dim3(1024), 0, s, w, t);
+    hipLaunchKernelGGL(k_bpe_merge, dim3(JTK_Q_SHARDS * ML_WGS_PER_SHARD), dim3(ML_THREADS), 0, s, w, t);
 }
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((w.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK)), dim3(1024), 0, s, w);

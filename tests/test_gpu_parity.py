@@ -630,6 +630,7 @@ def test_chunked_batches_equal_oracle(jt, in_flight):
         sp = docs.index(b"x <|endoftext|> y")
         b = enc.new_batch()
         b.set_option(N.JTK_OPT_CHUNK_BYTES, 64 * 1024)
+        b.set_option(N.JTK_OPT_HOST_CHUNK_BYTES, 96 * 1024)
         b.set_option(N.JTK_OPT_CHUNKS_IN_FLIGHT, in_flight)
         # device entry point
         d_text, d_off = torch.from_numpy(text2).to(dev), torch.from_numpy(off2).to(dev)
