@@ -331,9 +331,24 @@ def main():
     batch = new_batch(enc)
 
     after = None
-    if world > 1:
+    comm = None
+    if world > 1 and not rehearsal:
+        # the library's own RCCL communicator (jtk_comm_*); the unique id travels over the process group that launched us
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(sharding.Comm.unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(idt, 0)
+        comm = sharding.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+        d_global_off = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+
         def after(b):
-            # shard token totals -> every rank; exclusive prefix = this shard's global token offset (same stream as the encode)
+            # on the batch's stream, right behind the encode: ncclAllGather of the shard token totals (1 x int64 per rank),
+            # base = exclusive prefix, global offsets = local + base -- nothing waits for the host
+            _, off_ptr, _ = b.device_result()
+            comm.stitch(off_ptr, n_docs, d_global_off.data_ptr(), b.stream())
+    elif world > 1:
+        def after(b):
+            # rehearsal on one GPU (gloo): same step through torch.distributed
             _, off_ptr, _ = b.device_result()
             g_off = torch.as_tensor(_DevArray(off_ptr, n_docs + 1, "<i8"), device=dev)
             _, base = sharding.gather_shard_totals(g_off[-1:])
@@ -356,6 +371,12 @@ def main():
     t_max = float(allst[:, 0].max())
     total_bytes = float(allst[:, 1].sum())
 
+    # after the clock: the stitch's result (every rank sees every total; bases are their exclusive prefix)
+    if comm is not None:
+        totals, base = comm.fetch(batch.stream())
+        assert int(totals[rank]) == nt and int(base) == int(totals[:rank].sum())
+        g = d_global_off.cpu().numpy()
+        assert g[0] == base and g[-1] == base + nt
     # after the clock: this rank's result against the oracle (1 % of the documents, at most 10,000)
     verified = None
     if not args.no_verify:
@@ -410,6 +431,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.encoding, text, doc_off, max_threads=args.cpu_threads, ordinary=args.ordinary)
         print(json.dumps(out), flush=True)
     batch.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -195,6 +195,32 @@ int jtk_batch_decode_fetch(jtk_batch* b, uint8_t* out, int64_t out_cap, int64_t*
 /* Device pointers of the last decode (valid until the next decode on this batch). */
 int jtk_batch_decode_device_result(jtk_batch* b, const uint8_t** d_out, const int64_t** d_byte_off, const int32_t** d_status);
 
+/* ---- multi-GPU: document shards and the offset stitch ------------------------------------------------------------
+ * Documents are independent (every Encoding.encode call is a pure function of one string, GptBytePairEncoding.java:71-103),
+ * so a batch shards as contiguous document ranges balanced by bytes, one per GPU / process, each process with its own
+ * jtk_encoding (the rank tables are a few MB) and jtk_batch.  The one exchange step is an RCCL all-gather of the per-shard
+ * token totals (1 x int64 per rank, over xGMI); the exclusive prefix is the shard's first global token.  RCCL is bound at
+ * run time (librccl.so; env JTK_RCCL_LIB), only when a communicator is created. */
+typedef struct jtk_comm jtk_comm;
+
+/* bounds[world + 1]: rank r encodes documents [bounds[r], bounds[r + 1]) (host arrays; doc_off has n_docs + 1 entries). */
+int jtk_shard_plan(const int64_t* doc_off, int64_t n_docs, int world, int64_t* bounds);
+/* ncclGetUniqueId: call on one rank, hand the 128 bytes to every rank by any side channel, then every rank creates its
+ * communicator (ncclCommInitRank; collective over the ranks). */
+int jtk_comm_unique_id(uint8_t* id128);
+int jtk_comm_create(const uint8_t* id128, int world, int rank, int device, jtk_comm** out);
+void jtk_comm_destroy(jtk_comm* c);
+int jtk_comm_world(const jtk_comm* c);
+int jtk_comm_rank(const jtk_comm* c);
+/* The stitch, queued on `stream` (e.g. jtk_batch_stream() right after a non-synchronising jtk_batch_encode_device; nothing
+ * waits for the host): all-gather of d_tok_off[n_docs] (this shard's token total), base = sum of the lower ranks' totals,
+ * d_global_off[d] = d_tok_off[d] + base for d = 0..n_docs (d_global_off may be NULL: totals and base only).
+ * *d_totals (world entries) and *d_base (1 entry) are the communicator's device buffers. */
+int jtk_comm_stitch(jtk_comm* c, const int64_t* d_tok_off, int64_t n_docs, int64_t* d_global_off, void* stream,
+                    const int64_t** d_totals, const int64_t** d_base);
+/* Synchronises `stream` and copies the last stitch's totals[world] and base to the host. */
+int jtk_comm_fetch(jtk_comm* c, void* stream, int64_t* totals, int64_t* base);
+
 #define JTK_MAX_PIECE_BYTES (1 << 20)
 
 #ifdef __cplusplus

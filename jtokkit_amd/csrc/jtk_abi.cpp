@@ -51,6 +51,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+int jtk_fail_msg(int code, const std::string& msg) { return fail(code, msg); }      // for jtk_comm.cpp
+
 struct jtk_encoding {
     JtkHostTables host;
     int device = 0;

@@ -166,6 +166,8 @@ void jtk_launch_decode_scatter(const JtkDecodeWork& w, hipStream_t s);   // scat
 // chunk plan of a batch whose offsets are in device memory: out_doc[c], out_off[c] for c = 0..n_chunks
 void jtk_launch_plan_chunks(const int64_t* doc_off, int64_t n_docs, int64_t chunk_bytes, int n_chunks, int64_t* out_doc, int64_t* out_off,
                             hipStream_t s);
+void jtk_launch_stitch(const int64_t* totals, int rank, int64_t* base_out, const int64_t* tok_off, int64_t n_docs, int64_t* global_off,
+                       hipStream_t s);
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);

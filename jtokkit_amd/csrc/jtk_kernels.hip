@@ -1648,6 +1648,21 @@ void jtk_launch_plan_chunks(const int64_t* doc_off, int64_t n_docs, int64_t chun
                        out_doc, out_off);
 }
 
+// offset stitch of a sharded batch: base = sum of the lower ranks' token totals; global offsets = local offsets + base
+__global__ void __launch_bounds__(256) k_stitch(const int64_t* totals, int rank, int64_t* base_out, const int64_t* tok_off, int64_t n_docs,
+                                                int64_t* global_off) {
+    int64_t base = 0;
+    for (int r = 0; r < rank; r++) base += totals[r];
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d == 0) *base_out = base;
+    if (global_off && d <= n_docs) global_off[d] = tok_off[d] + base;
+}
+void jtk_launch_stitch(const int64_t* totals, int rank, int64_t* base_out, const int64_t* tok_off, int64_t n_docs, int64_t* global_off,
+                       hipStream_t s) {
+    const int64_t n = global_off ? n_docs + 1 : 1;
+    hipLaunchKernelGGL(k_stitch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, totals, rank, base_out, tok_off, n_docs, global_off);
+}
+
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s) {
     const int64_t n = w.n_docs + 1;
     hipLaunchKernelGGL(k_mark_docs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w);

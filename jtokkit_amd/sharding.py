@@ -6,7 +6,69 @@ bytes, one range per rank / GPU, each rank holding its own copy of the rank tabl
 is one all-gather of the per-shard token totals (RCCL over xGMI when the backend is "nccl"; gloo in
 the CPU tests); the exclusive prefix of the totals is the shard's global token offset.
 """
+import ctypes as C
+
 import numpy as np
+
+
+def shard_plan(doc_off, world_size):
+    """jtk_shard_plan (C ABI): the same byte-balanced contiguous ranges as shard_by_bytes, computed by the library."""
+    from . import _native as N
+    doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+    bounds = np.zeros(world_size + 1, dtype=np.int64)
+    rc = N.lib().jtk_shard_plan(doc_off.ctypes.data, len(doc_off) - 1, world_size, bounds.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("jtk_shard_plan: " + N.last_error())
+    return [int(b) for b in bounds]
+
+
+class Comm:
+    """jtk_comm: an RCCL communicator (one rank per process / GPU) for the offset stitch of a sharded batch."""
+
+    @staticmethod
+    def unique_id():
+        from . import _native as N
+        buf = (C.c_uint8 * 128)()
+        rc = N.lib().jtk_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("jtk_comm_unique_id: " + N.last_error())
+        return bytes(buf)
+
+    def __init__(self, unique_id, world, rank, device):
+        from . import _native as N
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = N.lib().jtk_comm_create(buf, world, rank, device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("jtk_comm_create: " + N.last_error())
+        self._h = h
+        self.world, self.rank = world, rank
+
+    def stitch(self, d_tok_off_ptr, n_docs, d_global_off_ptr, stream):
+        """Queued on `stream`: all-gather of the shard totals, base, global offsets.  Returns device pointers (totals, base)."""
+        from . import _native as N
+        a, b = C.c_void_p(), C.c_void_p()
+        rc = N.lib().jtk_comm_stitch(self._h, d_tok_off_ptr, n_docs, d_global_off_ptr, stream, C.byref(a), C.byref(b))
+        if rc != 0:
+            raise RuntimeError("jtk_comm_stitch: " + N.last_error())
+        return a.value, b.value
+
+    def fetch(self, stream):
+        from . import _native as N
+        totals = np.zeros(self.world, dtype=np.int64)
+        base = C.c_int64(0)
+        rc = N.lib().jtk_comm_fetch(self._h, stream, totals.ctypes.data, C.byref(base))
+        if rc != 0:
+            raise RuntimeError("jtk_comm_fetch: " + N.last_error())
+        return totals, base.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            from . import _native as N
+            N.lib().jtk_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def shard_by_bytes(doc_off, world_size):

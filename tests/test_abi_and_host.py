@@ -170,3 +170,16 @@ def test_corpus_generators_are_deterministic_and_valid():
     assert len(o1) == 1001 and t1.max() < 128
     bounds = corpus.shard_by_bytes(off, 4)
     assert bounds[0] == 0 and bounds[-1] == len(off) - 1 and bounds == sorted(bounds)
+
+
+def test_shard_plan_matches_python_reference():
+    """jtk_shard_plan (host-only entry point of the C ABI): contiguous document ranges balanced by bytes."""
+    from jtokkit_amd import corpus, sharding
+    text, doc_off = corpus.mixed(500, mean_bytes=900, lo=64, hi=8192, seed=17)
+    doc_off = np.concatenate([[0, 0], doc_off[1:], [doc_off[-1]]]).astype(np.int64)     # empty documents at both ends
+    for world in (1, 2, 3, 8):
+        b = sharding.shard_plan(doc_off, world)
+        assert b == sharding.shard_by_bytes(doc_off, world)
+        assert b[0] == 0 and b[-1] == len(doc_off) - 1 and all(x <= y for x, y in zip(b, b[1:]))
+        sizes = [int(doc_off[b[r + 1]] - doc_off[b[r]]) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 2 * 8192

@@ -660,3 +660,33 @@ def test_chunked_batches_equal_oracle(jt, in_flight):
             assert res.tokens[res.tok_off[d]:res.tok_off[d] + kept[d]].tolist() == e and bool(flag[d]) == tr, (name, d)
         hb.close()
         b.close()
+
+
+def test_comm_stitch_one_rank_rehearsal(jt):
+    """The N > 1 path behind the C ABI, rehearsed with a one-rank RCCL communicator on the one GPU of this box:
+    jtk_comm_unique_id / jtk_comm_create (ncclCommInitRank), then after a non-synchronising encode the stitch on the batch's
+    stream (ncclAllGather of the shard total, base, global offsets)."""
+    import torch
+    from jtokkit_amd import corpus, sharding
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = corpus.english(3000, seed=41)
+    bounds = sharding.shard_plan(doc_off, 2)
+    my_text, my_off, first = sharding.local_shard(text, doc_off, 1, 2)          # the second of two shards, as rank 1 would hold it
+    assert first == bounds[1]
+    dev = torch.device("cuda:0")
+    d_text, d_off = torch.from_numpy(np.ascontiguousarray(my_text)).to(dev), torch.from_numpy(np.ascontiguousarray(my_off)).to(dev)
+    torch.cuda.synchronize()
+    comm = sharding.Comm(sharding.Comm.unique_id(), 1, 0, 0)
+    b = enc.new_batch()
+    n_docs = len(my_off) - 1
+    g_off = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+    b.encode_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, len(my_text), ordinary=True, sync=False)
+    _, off_ptr, _ = b.device_result()
+    comm.stitch(off_ptr, n_docs, g_off.data_ptr(), b.stream())
+    totals, base = comm.fetch(b.stream())
+    exp_tok, exp_off = o.encode_batch(np.ascontiguousarray(my_text), np.ascontiguousarray(my_off), threads=8)
+    assert totals.tolist() == [len(exp_tok)] and base == 0
+    assert np.array_equal(g_off.cpu().numpy(), exp_off)
+    comm.close()
+    b.close()

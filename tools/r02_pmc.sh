@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 pass() {
   name=$1; shift
-  rocprofv3 --pmc "$@" -d $out/$name -o c --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --inflight 1 $BENCH_ARGS > $out/$name.log 2>&1
+  rocprofv3 --pmc "$@" -d $out/$name -o c --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-subrecords --serial $BENCH_ARGS > $out/$name.log 2>&1
   echo "pass $name done"
 }
 BENCH_ARGS="$*"
@@ -17,8 +17,10 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
+if [ -n "$PMC_CACHES" ]; then   # PMC_CACHES=1: also the cache counters (slow on large batches)
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum
+fi
 cd $root
 python3 tools/pmc_summary.py $out $out/summary.csv
 python3 - <<PY
