@@ -438,6 +438,39 @@ def main():
         dist.destroy_process_group()
 
 
+def per_call_record(args):
+    """tools/percall/percall_bench (built by __graft_entry__.build()): jtk_encode per document (direct), jtk_service_encode
+    (blocking callers coalesced into device batches), jtk_service_submit/wait (many documents in flight per thread) and, as
+    the CPU baseline of this shape, the oracle's per-call encode from the same number of threads."""
+    from jtokkit_amd import corpus
+    exe = os.path.join(ROOT, "tools", "percall", "percall_bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    rec = {"workload": "configs[0] corpus (1k short ASCII sentences) and 20k docs of configs[1], one call per document",
+           "unit": "documents/s (MB/s of input)", "runs": []}
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for name, (t, o) in (("cfg1", corpus.sentences(1000)), ("cfg2", corpus.english(20000))):
+        path = "/tmp/jtk_percall_%s_%d.bin" % (name, os.getpid())
+        with open(path, "wb") as f:
+            f.write(np.int64(len(o) - 1).tobytes())
+            f.write(o.tobytes())
+            f.write(t.tobytes())
+        for threads, in_flight in ((16, 1), (64, 1), (4, 1024)):
+            p = subprocess.run([exe, os.path.join(ROOT, "jtokkit_amd", "libjtokkit_amd.so"),
+                                "-" if args.no_cpu_baseline else os.path.join(ROOT, "oracle", "libjtk_oracle.so"),
+                                os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken"), path, str(threads), str(in_flight), "1"],
+                               capture_output=True, text=True, env=env, timeout=120)
+            if p.returncode != 0:
+                rec["runs"].append({"corpus": name, "threads": threads, "error": p.stderr[-300:]})
+                continue
+            r = json.loads(p.stdout)
+            r["corpus"] = name
+            rec["runs"].append(r)
+        os.unlink(path)
+    return rec
+
+
 def batch_chunks(batch, n_bytes, args):
     """The chunk count the library used for a batch of n_bytes (same rule as jtk_batch_encode_device)."""
     cb = (args.chunk_mb or 1024) << 20
@@ -554,6 +587,11 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, d_t
                              "verified": None if ns is None else "%d sampled documents == CPU oracle" % ns}
         b4.close()
         del d_t4, d_o4, t4, o4
+
+    # ---- the reference's per-call shape (one Encoding.encode call per document from a pool of threads,
+    # benchmark/.../AbstractMultiThreadedBenchmark.java:35-45) through the C ABI, driven by native threads
+    if wl_name == "cfg3":
+        out["per_call"] = per_call_record(args)
 
     # ---- vocabulary stress: documents of uniformly random rank-table entries (the lookups miss the caches realistically)
     if wl_name != "vocab":

@@ -195,6 +195,27 @@ int jtk_batch_decode_fetch(jtk_batch* b, uint8_t* out, int64_t out_cap, int64_t*
 /* Device pointers of the last decode (valid until the next decode on this batch). */
 int jtk_batch_decode_device_result(jtk_batch* b, const uint8_t** d_out, const int64_t** d_byte_off, const int32_t** d_status);
 
+/* ---- per-call service: many caller threads, one device batch at a time -------------------------------------------
+ * The reference is called per document from many threads (api/Encoding.java; its benchmark is one task per document on a
+ * pool of 1..64 threads, benchmark/.../AbstractMultiThreadedBenchmark.java:35-45).  A jtk_service coalesces such callers:
+ * whatever is queued when a worker becomes free is encoded as ONE device batch (no timer; while a batch is on the device
+ * the next one piles up), and every caller gets its own tokens back.  Thread-safe.  n_workers (default 2) worker threads,
+ * each with its own jtk_batch, so that the gathering of one batch overlaps the device time of another.
+ *   jtk_service_encode   blocking: Encoding.encode / encodeOrdinary / countTokens (flags as for jtk_batch_encode;
+ *                        max_tokens < 0 = no limit) -- same results and status codes as jtk_encode
+ *   jtk_service_submit / jtk_service_wait   the same in two halves, so that one thread can keep many documents in flight;
+ *                        utf8 and tokens must stay valid until the wait returns; every ticket must be waited for once */
+typedef struct jtk_service jtk_service;
+typedef struct jtk_ticket jtk_ticket;
+int jtk_service_create(const jtk_encoding* enc, int n_workers, jtk_service** out);
+void jtk_service_destroy(jtk_service* s);
+int jtk_service_encode(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
+                       int32_t* tokens, int64_t tokens_cap, int64_t* n_tokens, int* truncated);
+int jtk_service_submit(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
+                       int32_t* tokens, int64_t tokens_cap, jtk_ticket** ticket);
+int jtk_service_wait(jtk_service* s, jtk_ticket* ticket, int64_t* n_tokens, int* truncated);
+int jtk_service_stats(jtk_service* s, int64_t* n_batches, int64_t* n_docs);     /* device batches run, documents encoded */
+
 /* ---- multi-GPU: document shards and the offset stitch ------------------------------------------------------------
  * Documents are independent (every Encoding.encode call is a pure function of one string, GptBytePairEncoding.java:71-103),
  * so a batch shards as contiguous document ranges balanced by bytes, one per GPU / process, each process with its own

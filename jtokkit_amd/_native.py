@@ -67,6 +67,12 @@ SIGNATURES = {
     "jtk_batch_decode_device": (C.c_int, [_p, _p, _p, _i64, _i64, _p, C.POINTER(_i64)]),
     "jtk_batch_decode_fetch": (C.c_int, [_p, _p, _i64, _p, _p]),
     "jtk_batch_decode_device_result": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
+    "jtk_service_create": (C.c_int, [_p, C.c_int, C.POINTER(_p)]),
+    "jtk_service_destroy": (None, [_p]),
+    "jtk_service_encode": (C.c_int, [_p, _p, _i64, C.c_uint32, _i64, _p, _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "jtk_service_submit": (C.c_int, [_p, _p, _i64, C.c_uint32, _i64, _p, _i64, C.POINTER(_p)]),
+    "jtk_service_wait": (C.c_int, [_p, _p, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "jtk_service_stats": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "jtk_shard_plan": (C.c_int, [_p, _i64, C.c_int, _p]),
     "jtk_comm_unique_id": (C.c_int, [_p]),
     "jtk_comm_create": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),

@@ -62,6 +62,9 @@ struct jtk_encoding {
     std::vector<uint32_t> tok_len;   // byte length per id (0 = absent), for the maxTokens back-off
 };
 
+int64_t jtk_max_tokens_backoff(const jtk_encoding* enc, const uint8_t* utf8, int64_t len, const int32_t* head, int64_t nt,
+                               int64_t max_tokens, int* truncated);
+
 // One chunk in flight: a stream and the scratch of the kernels (sized for the largest chunk it has seen).
 struct ChunkSet {
     hipStream_t stream = nullptr;
@@ -74,6 +77,7 @@ struct ChunkSet {
 };
 
 constexpr int MAX_SETS = 4;
+constexpr int64_t SMALL_JOB_BYTES = 1 << 20;
 
 struct jtk_batch {
     const jtk_encoding* enc = nullptr;
@@ -437,9 +441,12 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
     if (to_host) {
         if ((rc = ensure_pinned((void**)&b->h_tok_off, &b->h_tok_off_cap, ((size_t)n_docs + 1) * 8, 0)) ||
             (rc = ensure_pinned((void**)&b->h_status, &b->h_status_cap, (size_t)(n_docs > 0 ? n_docs : 1) * 4, 0)) ||
-            (rc = ensure_pinned((void**)&b->h_tokens, &b->h_tokens_cap, (size_t)n_bytes * 2 + 4096, 0)))     // grown as the chunks report
+            (rc = ensure_pinned((void**)&b->h_tokens, &b->h_tokens_cap, (size_t)n_bytes * (n_bytes <= SMALL_JOB_BYTES ? 4 : 2) + 4096, 0)))     // grown as the chunks report
             return rc;
     }
+    // a small single-chunk job (the per-call service's batches) copies the worst-case token range (one token per byte) right
+    // behind the kernels instead of waiting for the count first: one host synchronisation less per batch
+    const bool small_to_host = to_host && n_chunks == 1 && n_bytes <= SMALL_JOB_BYTES;
     const bool prof = b->profiling;
     if (prof) {
         const size_t need = (size_t)n_chunks * N_STAGES * 2;
@@ -531,14 +538,16 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         jtk_launch_doc_offsets(w, cst);
         end();
         HIP_TRY(hipGetLastError());
+        if (small_to_host && n_bytes > 0 && !(flags & JTK_ENCODE_COUNT_ONLY))
+            HIP_TRY(hipMemcpyAsync(b->h_tokens, b->tokens.p, (size_t)n_bytes * 4, hipMemcpyDeviceToHost, cst));
         if (fork) HIP_TRY(hipEventRecord(cs.ev_done, cst));
-        if (to_host && c > 0) { if ((rc = send_chunk_to_host(c - 1)) != JTK_OK) return rc; }
+        if (to_host && !small_to_host && c > 0) { if ((rc = send_chunk_to_host(c - 1)) != JTK_OK) return rc; }
     }
-    if (to_host && n_chunks > 0) { if ((rc = send_chunk_to_host(n_chunks - 1)) != JTK_OK) return rc; }
+    if (to_host && !small_to_host && n_chunks > 0) { if ((rc = send_chunk_to_host(n_chunks - 1)) != JTK_OK) return rc; }
     if (fork) {
         for (int k = 0; k < n_sets; k++)
             if (b->set[k].used) HIP_TRY(hipStreamWaitEvent(s, b->set[k].ev_done, 0));
-        if (to_host) {
+        if (to_host && !small_to_host) {
             HIP_TRY(hipEventRecord(b->ev_copy, b->copy_stream));
             HIP_TRY(hipStreamWaitEvent(s, b->ev_copy, 0));
         }
@@ -853,6 +862,44 @@ static int64_t utf16_len(const uint8_t* s, int64_t n) {
     return k;
 }
 
+}  // extern "C"
+
+// Encoding.encode(text, maxTokens) from the full token list of `text` (GptBytePairEncoding.java:90-100): the first
+// min(maxTokens, nt) tokens, backed off until decode(tokens) is a prefix of the text.  head: at least that many leading
+// tokens.  Returns the count kept; *truncated = EncodingResult.isTruncated().
+int64_t jtk_max_tokens_backoff(const jtk_encoding* enc, const uint8_t* utf8, int64_t len, const int32_t* head, int64_t nt,
+                               int64_t max_tokens, int* truncated) {
+    int64_t keep = nt < max_tokens ? nt : max_tokens;
+    std::vector<int64_t> cum((size_t)keep + 1, 0);
+    for (int64_t k = 0; k < keep; k++) cum[(size_t)k + 1] = cum[(size_t)k] + enc->tok_len[(size_t)head[(size_t)k]];
+    const int64_t text16 = utf16_len(utf8, len);
+    if (truncated) *truncated = 0;
+    for (;; keep--) {
+        // decode(tokens) is the byte prefix [0, nb) of the text.  text.startsWith(decoded) holds when
+        // nb is a code-point boundary, or when the cut character decodes to one U+FFFD and the text
+        // has U+FFFD there.
+        const int64_t nb = cum[(size_t)keep];
+        const bool boundary = (nb == len) || ((utf8[nb] & 0xC0) != 0x80);
+        int64_t dec16;
+        bool starts;
+        if (boundary) { dec16 = utf16_len(utf8, nb); starts = true; }
+        else {
+            int64_t c = nb;
+            while (c > 0 && (utf8[c] & 0xC0) == 0x80) c--;
+            dec16 = utf16_len(utf8, c) + 1;
+            starts = (c + 2 < len) && utf8[c] == 0xEF && utf8[c + 1] == 0xBF && utf8[c + 2] == 0xBD;
+        }
+        if (starts) {
+            if (truncated) *truncated = text16 > dec16;
+            break;
+        }
+        if (keep == 0) break;
+    }
+    return keep;
+}
+
+extern "C" {
+
 int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
                int32_t* tokens, int64_t tokens_cap, int64_t* n_tokens, int* truncated) {
     if (!b || len < 0) return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
@@ -880,30 +927,9 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     int64_t keep = nt < max_tokens ? nt : max_tokens;
     std::vector<int32_t> head((size_t)(keep > 0 ? keep : 1));
     if (keep > 0) HIP_TRY(hipMemcpy(head.data(), b->tokens.p, (size_t)keep * 4, hipMemcpyDeviceToHost));
-    std::vector<int64_t> cum((size_t)keep + 1, 0);
-    for (int64_t k = 0; k < keep; k++) cum[(size_t)k + 1] = cum[(size_t)k] + b->enc->tok_len[(size_t)head[(size_t)k]];
-    const int64_t text16 = utf16_len(utf8, len);
-    for (;; keep--) {
-        // decode(tokens) is the byte prefix [0, nb) of the text.  text.startsWith(decoded) holds when
-        // nb is a code-point boundary, or when the cut character decodes to one U+FFFD and the text
-        // has U+FFFD there.
-        const int64_t nb = cum[(size_t)keep];
-        const bool boundary = (nb == len) || ((utf8[nb] & 0xC0) != 0x80);
-        int64_t dec16;
-        bool starts;
-        if (boundary) { dec16 = utf16_len(utf8, nb); starts = true; }
-        else {
-            int64_t c = nb;
-            while (c > 0 && (utf8[c] & 0xC0) == 0x80) c--;
-            dec16 = utf16_len(utf8, c) + 1;
-            starts = (c + 2 < len) && utf8[c] == 0xEF && utf8[c + 1] == 0xBF && utf8[c + 2] == 0xBD;
-        }
-        if (starts) {
-            if (truncated) *truncated = text16 > dec16;
-            break;
-        }
-        if (keep == 0) break;
-    }
+    int tr = 0;
+    keep = jtk_max_tokens_backoff(b->enc, utf8, len, head.data(), nt, max_tokens, &tr);
+    if (truncated) *truncated = tr;
     if (n_tokens) *n_tokens = keep;
     if (tokens) {
         if (tokens_cap < keep) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");

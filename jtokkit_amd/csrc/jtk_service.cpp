@@ -1,0 +1,237 @@
+// jtk_service.cpp -- the per-call shape of the reference behind the batch path.
+//
+// The reference is called one document at a time from many threads (api/Encoding.java; its benchmark,
+// benchmark/.../AbstractMultiThreadedBenchmark.java:35-45, is one task per document on a pool of 1..64 threads).  One GPU
+// encode per call would pay copies, a dozen launches and a synchronisation per document.  A jtk_service coalesces instead:
+// callers hand their document to a queue and block; worker threads (each with its own jtk_batch) take EVERYTHING that is
+// queued at that moment -- no timer: while a batch is on the device the next one piles up -- gather it into pinned memory,
+// run ONE batch encode with the result streamed back to pinned host memory, and hand every caller its tokens.
+// jtk_service_submit / jtk_service_wait are the same without blocking in between, so that one thread can keep thousands of
+// documents in flight (a Java shim's CompletableFuture).
+#include <hip/hip_runtime.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <climits>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/jtokkit_amd.h"
+
+int jtk_fail_msg(int code, const std::string& msg);
+struct jtk_encoding;
+int64_t jtk_max_tokens_backoff(const jtk_encoding* enc, const uint8_t* utf8, int64_t len, const int32_t* head, int64_t nt,
+                               int64_t max_tokens, int* truncated);
+
+struct jtk_ticket {
+    const uint8_t* utf8 = nullptr;
+    int64_t len = 0;
+    uint32_t flags = 0;
+    int64_t max_tokens = -1;
+    int32_t* tokens = nullptr;
+    int64_t cap = 0;
+    // result
+    int64_t n_tokens = 0;
+    int truncated = 0;
+    int status = JTK_OK;
+    std::atomic<int> done{0};        // set by the worker (release); the waiter spins briefly, then sleeps on it (futex)
+    std::atomic<int> sleeping{0};
+};
+
+struct jtk_service {
+    const jtk_encoding* enc = nullptr;
+    int device = 0;
+    int64_t max_docs = 1 << 16, max_bytes = (int64_t)64 << 20;
+    std::mutex mu;                    // guards `queue` only: a producer holds it for one push_back
+    std::vector<jtk_ticket*> queue;
+    std::atomic<int> pending{0};      // documents queued; idle workers sleep on it (futex)
+    std::atomic<int> idle{0};
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> workers;
+    std::atomic<int64_t> n_batches{0}, n_docs{0};
+};
+
+namespace {
+
+long futex_wait(std::atomic<int>* a, int expected) {
+    return syscall(SYS_futex, reinterpret_cast<int*>(a), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+long futex_wake(std::atomic<int>* a, int n) {
+    return syscall(SYS_futex, reinterpret_cast<int*>(a), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
+}
+
+void worker_main(jtk_service* s) {
+    (void)hipSetDevice(s->device);
+    jtk_batch* b = nullptr;
+    uint8_t* h_text = nullptr;
+    size_t h_text_cap = 0;
+    int64_t* doc_off = nullptr;           // pinned too: the offsets go to the device by DMA like the text
+    size_t doc_off_cap = 0;
+    std::vector<jtk_ticket*> take, group;
+    int create_rc = jtk_batch_create(s->enc, &b);
+    for (;;) {
+        take.clear();
+        // everything that is queued right now (no timer: while this batch is on the device the next one piles up)
+        while (s->pending.load(std::memory_order_acquire) == 0) {
+            if (s->stop.load()) break;
+            s->idle.fetch_add(1);
+            if (s->pending.load() == 0 && !s->stop.load()) futex_wait(&s->pending, 0);
+            s->idle.fetch_sub(1);
+        }
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            take.swap(s->queue);
+            s->pending.store(0, std::memory_order_release);
+        }
+        if (take.empty()) { if (s->stop.load()) break; continue; }
+        // encode() and encodeOrdinary() callers (and count-only ones) form separate device batches
+        for (int pass = 0; pass < 4 && !take.empty(); pass++) {
+            const uint32_t want = (pass & 1 ? JTK_ENCODE_ORDINARY : 0u) | (pass & 2 ? JTK_ENCODE_COUNT_ONLY : 0u);
+            group.clear();
+            for (jtk_ticket* t : take)
+                if ((t->flags & (JTK_ENCODE_ORDINARY | JTK_ENCODE_COUNT_ONLY)) == want) group.push_back(t);
+            if (group.empty()) continue;
+            int rc = create_rc;
+            if (rc == JTK_OK && group.size() + 1 > doc_off_cap) {
+                if (doc_off) jtk_host_free(doc_off);
+                doc_off = nullptr;
+                doc_off_cap = group.size() * 2 + 1024;
+                rc = jtk_host_alloc(doc_off_cap * 8, (void**)&doc_off);
+                if (rc != JTK_OK) doc_off_cap = 0;
+            }
+            int64_t total = 0;
+            if (rc == JTK_OK) {
+                doc_off[0] = 0;
+                for (size_t i = 0; i < group.size(); i++) { total += group[i]->len; doc_off[i + 1] = total; }
+            }
+            if (rc == JTK_OK && (size_t)total + 64 > h_text_cap) {
+                if (h_text) jtk_host_free(h_text);
+                h_text = nullptr;
+                h_text_cap = (size_t)total * 2 + 4096;
+                rc = jtk_host_alloc(h_text_cap, (void**)&h_text);
+                if (rc != JTK_OK) h_text_cap = 0;
+            }
+            const int32_t* r_tok = nullptr;
+            const int64_t* r_off = nullptr;
+            const int32_t* r_st = nullptr;
+            if (rc == JTK_OK) {
+                for (size_t i = 0; i < group.size(); i++)
+                    if (group[i]->len) memcpy(h_text + doc_off[i], group[i]->utf8, (size_t)group[i]->len);
+                int64_t nt = 0;
+                rc = jtk_batch_encode(b, h_text, doc_off, (int64_t)group.size(), want | JTK_ENCODE_TO_HOST, &nt);
+                if (rc == JTK_OK) rc = jtk_batch_host_result(b, &r_tok, &r_off, &r_st);
+            }
+            for (size_t i = 0; i < group.size(); i++) {
+                jtk_ticket* t = group[i];
+                t->status = rc;
+                if (rc != JTK_OK) continue;
+                if (r_st[i] != JTK_OK) { t->status = r_st[i]; continue; }
+                int64_t n = r_off[i + 1] - r_off[i];
+                if (t->max_tokens >= 0 && !(want & JTK_ENCODE_COUNT_ONLY))
+                    n = jtk_max_tokens_backoff(s->enc, t->utf8, t->len, r_tok + r_off[i], n, t->max_tokens, &t->truncated);
+                t->n_tokens = n;
+                if (t->tokens && !(want & JTK_ENCODE_COUNT_ONLY)) {
+                    if (t->cap < n) t->status = JTK_ERR_CAPACITY;
+                    else if (n > 0) memcpy(t->tokens, r_tok + r_off[i], (size_t)n * 4);
+                }
+            }
+            s->n_batches++;
+            s->n_docs += (int64_t)group.size();
+        }
+        for (jtk_ticket* t : take) {
+            t->done.store(1, std::memory_order_seq_cst);
+            if (t->sleeping.load(std::memory_order_seq_cst)) futex_wake(&t->done, 1);
+        }
+    }
+    if (h_text) jtk_host_free(h_text);
+    if (doc_off) jtk_host_free(doc_off);
+    if (b) jtk_batch_destroy(b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int jtk_service_create(const jtk_encoding* enc, int n_workers, jtk_service** out) {
+    if (!enc || !out) return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    if (n_workers <= 0) n_workers = 2;
+    if (n_workers > 16) n_workers = 16;
+    jtk_service* s = new (std::nothrow) jtk_service();
+    if (!s) return jtk_fail_msg(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
+    s->enc = enc;
+    s->device = jtk_encoding_device(enc);
+    for (int i = 0; i < n_workers; i++) s->workers.emplace_back(worker_main, s);
+    *out = s;
+    return JTK_OK;
+}
+
+void jtk_service_destroy(jtk_service* s) {
+    if (!s) return;
+    s->stop.store(true);
+    s->pending.fetch_add(1);                                     // wakes idle workers; they find an empty queue and leave
+    futex_wake(&s->pending, INT_MAX);
+    for (auto& t : s->workers) t.join();
+    delete s;
+}
+
+int jtk_service_submit(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
+                       int32_t* tokens, int64_t tokens_cap, jtk_ticket** ticket) {
+    if (!s || !ticket || len < 0 || (len > 0 && !utf8)) return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    jtk_ticket* t = new (std::nothrow) jtk_ticket();
+    if (!t) return jtk_fail_msg(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
+    t->utf8 = utf8; t->len = len; t->flags = flags & (JTK_ENCODE_ORDINARY | JTK_ENCODE_COUNT_ONLY); t->max_tokens = max_tokens;
+    t->tokens = tokens; t->cap = tokens_cap;
+    if (s->stop.load()) { delete t; return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "service is shutting down"); }
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->queue.push_back(t);
+        s->pending.fetch_add(1, std::memory_order_release);
+    }
+    if (s->idle.load(std::memory_order_seq_cst) > 0) futex_wake(&s->pending, 1);
+    *ticket = t;
+    return JTK_OK;
+}
+
+int jtk_service_wait(jtk_service* s, jtk_ticket* t, int64_t* n_tokens, int* truncated) {
+    if (!s || !t) return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    for (int spin = 0; spin < 2000 && !t->done.load(std::memory_order_acquire); spin++) __builtin_ia32_pause();
+    if (!t->done.load(std::memory_order_acquire)) {
+        t->sleeping.store(1, std::memory_order_seq_cst);
+        while (!t->done.load(std::memory_order_seq_cst)) futex_wait(&t->done, 0);
+    }
+    const int rc = t->status;
+    if (n_tokens) *n_tokens = t->n_tokens;
+    if (truncated) *truncated = t->truncated;
+    delete t;
+    if (rc == JTK_ERR_UNSUPPORTED_SPECIAL) return jtk_fail_msg(rc, "Encoding special tokens is not supported yet.");
+    if (rc == JTK_ERR_CAPACITY) return jtk_fail_msg(rc, "tokens buffer too small");
+    if (rc != JTK_OK) return jtk_fail_msg(rc, "document could not be encoded");
+    return JTK_OK;
+}
+
+int jtk_service_encode(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
+                       int32_t* tokens, int64_t tokens_cap, int64_t* n_tokens, int* truncated) {
+    if (n_tokens) *n_tokens = 0;
+    if (truncated) *truncated = 0;
+    if (s && !utf8 && len == 0) return JTK_OK;                   // text == null -> empty result (GptBytePairEncoding.java:48-50)
+    jtk_ticket* t = nullptr;
+    int rc = jtk_service_submit(s, utf8, len, flags, max_tokens, tokens, tokens_cap, &t);
+    if (rc != JTK_OK) return rc;
+    return jtk_service_wait(s, t, n_tokens, truncated);
+}
+
+int jtk_service_stats(jtk_service* s, int64_t* n_batches, int64_t* n_docs) {
+    if (!s) return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "service is NULL");
+    if (n_batches) *n_batches = s->n_batches.load();
+    if (n_docs) *n_docs = s->n_docs.load();
+    return JTK_OK;
+}
+
+}  // extern "C"

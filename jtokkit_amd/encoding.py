@@ -7,6 +7,7 @@ so this Python class (and the C++ header jtokkit_amd/csrc/jtk_encoding.hpp) stan
 `HipEncoding implements Encoding` of INTEGRATION.md would.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -244,11 +245,16 @@ class HipEncoding:
         self._h = h
         self._name = name
         self._batch = None
+        self._svc = None
+        self._svc_lock = threading.Lock()
 
     def close(self):
         if self._batch is not None:
             self._batch.close()
             self._batch = None
+        if getattr(self, "_svc", None):
+            N.lib().jtk_service_destroy(self._svc)
+            self._svc = None
         if getattr(self, "_h", None):
             N.lib().jtk_encoding_destroy(self._h)
             self._h = None
@@ -268,12 +274,36 @@ class HipEncoding:
         return self._batch
 
     # ---- api/Encoding.java ---------------------------------------------------------------------------
+    # "The encoding must be thread-safe" (api/EncodingRegistry.java:51,61): the per-call methods go through the
+    # encoding's jtk_service, which coalesces concurrent callers into device batches.
+    def _service(self):
+        if self._svc is None:
+            with self._svc_lock:
+                if self._svc is None:
+                    h = C.c_void_p()
+                    _check(N.lib().jtk_service_create(self._h, 2, C.byref(h)))
+                    self._svc = h
+        return self._svc
+
+    def _encode_one(self, text, ordinary, max_tokens):
+        if text is None:
+            return [], False
+        b = text if isinstance(text, (bytes, bytearray)) else text.encode("utf-8")
+        cap = len(b) + 1
+        out = np.empty(cap, dtype=np.int32)
+        nt = C.c_int64(0)
+        tr = C.c_int(0)
+        _check(N.lib().jtk_service_encode(self._service(), bytes(b), len(b), N.JTK_ENCODE_ORDINARY if ordinary else 0,
+                                          -1 if max_tokens is None else int(max_tokens), out.ctypes.data, cap,
+                                          C.byref(nt), C.byref(tr)))
+        return out[:nt.value].tolist(), bool(tr.value)
+
     def encode(self, text, max_tokens=None):                       # Encoding.java:29,61
-        toks, tr = self._b().encode_one(text, False, max_tokens)
+        toks, tr = self._encode_one(text, False, max_tokens)
         return toks if max_tokens is None else EncodingResult(toks, tr)
 
     def encode_ordinary(self, text, max_tokens=None):              # :80,107
-        toks, tr = self._b().encode_one(text, True, max_tokens)
+        toks, tr = self._encode_one(text, True, max_tokens)
         return toks if max_tokens is None else EncodingResult(toks, tr)
 
     def count_tokens(self, text):                                  # :127

@@ -690,3 +690,47 @@ def test_comm_stitch_one_rank_rehearsal(jt):
     assert np.array_equal(g_off.cpu().numpy(), exp_off)
     comm.close()
     b.close()
+
+
+def test_per_call_methods_from_many_threads(jt):
+    """The reference's calling shape: Encoding.encode(String) per document from a pool of threads
+    (benchmark/.../AbstractMultiThreadedBenchmark.java:35-45).  The per-call methods are thread-safe and coalesced into device
+    batches by the encoding's jtk_service; every caller gets exactly its own document's tokens (incl. maxTokens, the
+    special-token exception and empty strings)."""
+    import threading
+    from jtokkit_amd import corpus
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = corpus.sentences(1200, seed=51)
+    t2, o2 = corpus.mixed(300, mean_bytes=700, lo=64, hi=4096, seed=52)
+    docs = [text[doc_off[d]:doc_off[d + 1]].tobytes().decode() for d in range(len(doc_off) - 1)]
+    docs += [t2[o2[d]:o2[d + 1]].tobytes().decode() for d in range(len(o2) - 1)]
+    docs += ["", "x", "hello <|endoftext|> world"]
+    errors = []
+    n_threads = 12
+
+    def worker(t):
+        try:
+            for i in range(t, len(docs), n_threads):
+                d = docs[i]
+                if "<|endoftext|>" in d:
+                    with pytest.raises(jt.UnsupportedOperationError):
+                        enc.encode(d)
+                    assert enc.encode_ordinary(d) == o.encode_ordinary(d)
+                    continue
+                assert enc.encode(d) == o.encode(d), i
+                if i % 5 == 0:
+                    r = enc.encode(d, 9)
+                    e, tr = o.encode(d, 9)
+                    assert r.get_tokens() == e and r.is_truncated() == tr, i
+                if i % 7 == 0:
+                    assert enc.count_tokens(d) == len(o.encode(d))
+        except BaseException as ex:          # noqa: BLE001 -- reported to the main thread
+            errors.append((t, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[0]
