@@ -125,6 +125,15 @@ void jtk_host_free(void* p);
 int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs,
                      uint32_t flags, int64_t* n_tokens);
 
+/* Custom split patterns (api/GptBytePairEncodingParams.java:36-46: any java.util.regex.Pattern).  Only the two shipped
+ * patterns are evaluated on the device; for any other one the caller runs its own matcher on the host and hands over the
+ * matches: piece i is utf8[piece_begin[i], piece_end[i]) (positions in the whole batch; ascending, non-empty, not
+ * overlapping, each inside one document).  Bytes that no piece covers are not encoded, as `while (matcher.find())`
+ * (GptBytePairEncoding.java:79) skips them.  Whole-piece shortcut, bytePairMerge, token order, offsets, status, flags
+ * and results are as for jtk_batch_encode (the special-token check of encode() is done on the host here). */
+int jtk_batch_encode_pieces(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs,
+                            const int64_t* piece_begin, const int64_t* piece_end, int64_t n_pieces, uint32_t flags, int64_t* n_tokens);
+
 /* After an encode with JTK_ENCODE_TO_HOST: the result in the batch's pinned host buffers (valid until the next encode
  * on this batch): tokens[n_tokens], tok_off[n_docs + 1], status[n_docs]. */
 int jtk_batch_host_result(jtk_batch* b, const int32_t** tokens, const int64_t** tok_off, const int32_t** status);

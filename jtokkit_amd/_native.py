@@ -53,6 +53,7 @@ SIGNATURES = {
     "jtk_host_free": (None, [_p]),
     "jtk_batch_host_result": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "jtk_batch_encode": (C.c_int, [_p, _p, _p, _i64, C.c_uint32, C.POINTER(_i64)]),
+    "jtk_batch_encode_pieces": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, C.c_uint32, C.POINTER(_i64)]),
     "jtk_batch_encode_device": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_uint32, _p, C.POINTER(_i64)]),
     "jtk_batch_stream": (_p, [_p]),
     "jtk_batch_result": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32)]),

@@ -3,6 +3,7 @@
 // without a HIP device every encode entry point fails with JTK_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,7 +72,7 @@ struct ChunkSet {
     hipEvent_t ev_scan = nullptr;    // this set's tile_scan has run (the next chunk's scan waits for it: token order)
     hipEvent_t ev_done = nullptr;    // this set's last kernel has run
     DevBuf zeroed;                   // docmask | list counters | queue counters
-    DevBuf piecemask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list, giant_list, giant_cnt;
+    DevBuf piecemask, gapmask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list, giant_list, giant_cnt;
     JtkWork work{};
     bool used = false;               // by the current job
 };
@@ -93,6 +94,7 @@ struct jtk_batch {
     int64_t host_chunk_bytes = (int64_t)32 << 20;   // JTK_OPT_HOST_CHUNK_BYTES: host input (small chunks: copies overlap kernels)
     // the whole batch
     DevBuf in_text, in_off;          // device copy of host input (host-buffer entry point)
+    DevBuf in_pieces;                // caller-supplied pieces (jtk_batch_encode_pieces): begin[n] | end[n]
     DevBuf status, job;              // per document | JtkResult + running token totals per chunk
     DevBuf tokens, tok_off;
     DevBuf plan;                     // chunk plan of a device-resident batch
@@ -148,8 +150,10 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     if (n_specials > JTK_MAX_SPECIALS) return fail(JTK_ERR_INVALID_ARGUMENT, "too many special tokens");
     for (int i = 0; i < n_specials; i++) {
         const size_t l = strlen(special_literals[i]);
-        if (l < 2 || l > JTK_SPECIAL_MAXLEN || special_literals[i][0] != '<' || special_literals[i][1] != '|')
-            return fail(JTK_ERR_INVALID_ARGUMENT, "special-token literals must start with \"<|\" and be at most 32 bytes");
+        if (l < 1 || l > JTK_SPECIAL_MAXLEN)
+            return fail(JTK_ERR_INVALID_ARGUMENT, "special-token literals must be 1..32 bytes long");
+        if (special_ids[i] < 0 || special_ids[i] > (int32_t)JTK_MAX_ID + (1 << 20))
+            return fail(JTK_ERR_INVALID_ARGUMENT, "special-token id out of range");
     }
     jtk_encoding* enc = new (std::nothrow) jtk_encoding();
     if (!enc) return fail(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
@@ -280,14 +284,14 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ChunkSet& cs : b->set) {
         if (cs.stream) (void)hipStreamSynchronize(cs.stream);
-        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.plist, &cs.htok, &cs.docpre, &cs.tile_np, &cs.tile_off, &cs.queues, &cs.q_meta,
+        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.plist, &cs.htok, &cs.docpre, &cs.tile_np, &cs.tile_off, &cs.queues, &cs.q_meta,
                           &cs.mid_list, &cs.long_list, &cs.giant_list, &cs.giant_cnt};
         for (DevBuf* d : bufs) d->release();
         if (cs.ev_scan) (void)hipEventDestroy(cs.ev_scan);
         if (cs.ev_done) (void)hipEventDestroy(cs.ev_done);
         if (cs.stream) (void)hipStreamDestroy(cs.stream);
     }
-    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->status, &b->job, &b->tokens, &b->tok_off, &b->plan, &b->dec_in_ids, &b->dec_in_off,
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->in_pieces, &b->status, &b->job, &b->tokens, &b->tok_off, &b->plan, &b->dec_in_ids, &b->dec_in_off,
                       &b->dec_zero, &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag};
     for (DevBuf* d : bufs) d->release();
     for (hipEvent_t ev : b->prof_ev) (void)hipEventDestroy(ev);
@@ -422,8 +426,14 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
 // h_text != NULL: the text comes from host memory, copied chunk by chunk into in_text on the chunk's stream (so the copy of
 // chunk c + 1 overlaps the kernels of chunk c).  to_host: every chunk's tokens are copied to the pinned host buffer as
 // soon as they are packed.
+struct PieceArgs {               // caller-supplied pieces instead of pretok_split
+    const int64_t* d_begin; const int64_t* d_end;     // device copies
+    const int64_t* h_begin;                           // host: to find each chunk's pieces
+    int64_t n;
+};
+
 int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
-            uint32_t flags, hipStream_t s, bool to_host) {
+            uint32_t flags, hipStream_t s, bool to_host, const PieceArgs* pieces = nullptr) {
     const jtk_encoding* enc = b->enc;
     const int n_chunks = (int)b->chunk_doc.size() - 1;
     const int n_sets = n_chunks < b->n_sets ? (n_chunks < 1 ? 1 : n_chunks) : b->n_sets;
@@ -518,7 +528,19 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         if (flags & JTK_ENCODE_VALIDATE_UTF8) jtk_launch_validate_utf8(w, cst);
         end();
         begin();
-        jtk_launch_pretok_split(w, enc->dt, cst);
+        if (pieces) {
+            const size_t mask_bytes = (size_t)w.n_words * 8;
+            if ((rc = cs.gapmask.ensure(mask_bytes))) return rc;
+            w.gapmask = (uint64_t*)cs.gapmask.p;
+            HIP_TRY(hipMemsetAsync(cs.piecemask.p, 0, mask_bytes, cst));
+            HIP_TRY(hipMemsetAsync(cs.gapmask.p, 0, mask_bytes, cst));
+            const int64_t* pb = pieces->h_begin;
+            const int64_t p0 = std::lower_bound(pb, pb + pieces->n, b0) - pb, p1 = std::lower_bound(pb, pb + pieces->n, b1) - pb;
+            jtk_launch_mark_pieces(w, pieces->d_begin + p0, pieces->d_end + p0, p1 - p0, cst);
+        } else {
+            w.gapmask = nullptr;
+            jtk_launch_pretok_split(w, enc->dt, cst);
+        }
         end();
         begin();
         jtk_launch_piece_resolve(w, enc->dt, cst);
@@ -652,6 +674,90 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
                  b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
     if (rc != JTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
+    b->synced = true;
+    if (n_tokens) *n_tokens = b->host_result->n_tokens;
+    return JTK_OK;
+}
+
+int jtk_batch_encode_pieces(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs,
+                            const int64_t* piece_begin, const int64_t* piece_end, int64_t n_pieces, uint32_t flags, int64_t* n_tokens) {
+    if (!b || n_docs < 0 || !doc_off || n_pieces < 0 || (n_pieces > 0 && (!piece_begin || !piece_end)))
+        return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (doc_off[0] != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off[0] must be 0");
+    const int64_t n_bytes = doc_off[n_docs];
+    if (n_bytes > 0 && !utf8) return fail(JTK_ERR_INVALID_ARGUMENT, "utf8 is NULL");
+    if (n_bytes >= (int64_t)1 << 37) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large (128 GiB of text per call at most)");
+    // pieces: ascending, non-empty, non-overlapping, each inside one document
+    {
+        int64_t d = 0, prev_end = 0;
+        for (int64_t i = 0; i < n_pieces; i++) {
+            const int64_t p = piece_begin[i], e = piece_end[i];
+            if (p < prev_end || e <= p || e > n_bytes) return fail(JTK_ERR_INVALID_ARGUMENT, "pieces must be ascending, non-empty and non-overlapping");
+            while (d < n_docs && doc_off[d + 1] <= p) d++;
+            if (d >= n_docs || e > doc_off[d + 1]) return fail(JTK_ERR_INVALID_ARGUMENT, "a piece crosses a document boundary");
+            prev_end = e;
+        }
+    }
+    const int64_t cb = b->host_chunk_bytes < b->chunk_bytes ? b->host_chunk_bytes : b->chunk_bytes;
+    b->chunk_doc.assign(1, 0);
+    b->chunk_off.assign(1, 0);
+    {
+        int64_t next = cb;
+        for (int64_t d = 0; d < n_docs; d++) {
+            if (doc_off[d + 1] < doc_off[d]) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off must be non-decreasing");
+            if (doc_off[d] >= next && d > b->chunk_doc.back() && n_bytes - doc_off[d] > cb / 4) {
+                b->chunk_doc.push_back(d);
+                b->chunk_off.push_back(doc_off[d]);
+                next = doc_off[d] + cb;
+            }
+        }
+    }
+    b->chunk_doc.push_back(n_docs);
+    b->chunk_off.push_back(n_bytes);
+    HIP_TRY(hipSetDevice(b->enc->device));
+    int rc;
+    if ((rc = b->in_text.ensure((size_t)n_bytes + 64)) || (rc = b->in_off.ensure(((size_t)n_docs + 1) * 8)) ||
+        (rc = b->in_pieces.ensure((size_t)(n_pieces > 0 ? n_pieces : 1) * 16)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(b->in_off.p, doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    int64_t* d_begin = (int64_t*)b->in_pieces.p;
+    int64_t* d_end = d_begin + (n_pieces > 0 ? n_pieces : 1);
+    if (n_pieces > 0) {
+        HIP_TRY(hipMemcpyAsync(d_begin, piece_begin, (size_t)n_pieces * 8, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(d_end, piece_end, (size_t)n_pieces * 8, hipMemcpyHostToDevice, b->stream));
+    }
+    const PieceArgs pa{d_begin, d_end, piece_begin, n_pieces};
+    // the special-token check of encode() (GptBytePairEncoding.java:52-56, text.contains) rides in pretok_split on the device;
+    // with caller-supplied pieces that kernel does not run, so it is done here on the host
+    std::vector<int64_t> special_docs;
+    if (!(flags & JTK_ENCODE_ORDINARY)) {
+        for (auto& sp : b->enc->host.specials) {
+            const std::string& lit = sp.first;
+            if (lit.empty() || (int64_t)lit.size() > n_bytes) continue;
+            const uint8_t* p = utf8;
+            const uint8_t* endp = utf8 + n_bytes;
+            while (p < endp) {
+                const void* hit = memmem(p, (size_t)(endp - p), lit.data(), lit.size());
+                if (!hit) break;
+                const int64_t pos = (const uint8_t*)hit - utf8;
+                const int64_t d = (std::upper_bound(doc_off, doc_off + n_docs + 1, pos) - doc_off) - 1;
+                if (d >= 0 && d < n_docs && pos + (int64_t)lit.size() <= doc_off[d + 1]) special_docs.push_back(d);
+                p = (const uint8_t*)hit + 1;
+            }
+        }
+    }
+    rc = run_job(b, (const uint8_t*)b->in_text.p, utf8, (const int64_t*)b->in_off.p, n_docs, n_bytes,
+                 (flags | JTK_ENCODE_ORDINARY) & ~(uint32_t)JTK_ENCODE_TO_HOST, b->stream, (flags & JTK_ENCODE_TO_HOST) != 0, &pa);
+    if (rc != JTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (!special_docs.empty()) {
+        const int32_t st = JTK_ERR_UNSUPPORTED_SPECIAL;
+        for (int64_t d : special_docs) {
+            HIP_TRY(hipMemcpy((int32_t*)b->status.p + d, &st, 4, hipMemcpyHostToDevice));
+            if (b->have_host_result) b->h_status[d] = st;
+        }
+        if (b->host_result->worst_status > st) b->host_result->worst_status = st;
+    }
     b->synced = true;
     if (n_tokens) *n_tokens = b->host_result->n_tokens;
     return JTK_OK;

@@ -19,7 +19,7 @@ enum : uint32_t {
     JTK_F_L = 1u << 0, JTK_F_N = 1u << 1, JTK_F_W = 1u << 2, JTK_F_NL = 1u << 3, JTK_F_SP = 1u << 4, JTK_F_AP = 1u << 5,
     JTK_F_CONT = 1u << 6, JTK_F_LEAD = 1u << 7,          // LEAD: first byte of a non-ASCII character
     JTK_F_S1 = 1u << 8, JTK_F_RV = 1u << 9, JTK_F_E = 1u << 10, JTK_F_LL = 1u << 11, JTK_F_C5 = 1u << 12, JTK_F_BF = 1u << 13,
-    JTK_F_LT = 1u << 14                                   // '<': where a special-token literal can start
+    JTK_F_LT = 1u << 14                                   // a byte a special-token literal starts with (set by the kernel from the encoding's literals)
 };
 
 JTK_HD uint32_t jtk_byte_code(uint32_t b, bool case_insensitive) {
@@ -32,7 +32,6 @@ JTK_HD uint32_t jtk_byte_code(uint32_t b, bool case_insensitive) {
         if (b == '\r' || b == '\n') c |= JTK_F_NL;
         if (b == 0x20u) c |= JTK_F_SP;
         if (b == '\'') c |= JTK_F_AP;
-        if (b == '<') c |= JTK_F_LT;
         const uint32_t f = (case_insensitive && (b - 'A') < 26u) ? (b | 0x20u) : b;
         if (f == 's' || f == 't' || f == 'm' || f == 'd') c |= JTK_F_S1;
         if (f == 'r' || f == 'v') c |= JTK_F_RV;

@@ -98,6 +98,8 @@ struct JtkWork {
     uint32_t check_special; // encode(): flag documents that contain a special-token literal (done inside pretok_split)
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)
+    uint64_t* gapmask;      // NULL, or (caller-supplied pieces, jtk_batch_encode_pieces) bit p: the "piece" that starts at byte p is
+                            // text between two matches of the caller's pattern: it is not encoded (matcher.find() skips it)
     uint32_t* plist;        // [n_tiles * JTK_TILE] per tile, packed from the tile's first word: its pieces in text order,
                             // JTK_PL_* entry per piece (a piece belongs to the tile it starts in)
     uint32_t* tile_np;      // [n_tiles] pieces in each tile's list
@@ -169,6 +171,8 @@ void jtk_launch_plan_chunks(const int64_t* doc_off, int64_t n_docs, int64_t chun
 void jtk_launch_stitch(const int64_t* totals, int rank, int64_t* base_out, const int64_t* tok_off, int64_t n_docs, int64_t* global_off,
                        hipStream_t s);
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
+// caller-supplied pieces [begin[i], end[i]) (positions in the whole batch), i = 0..n_pieces-1, instead of pretok_split
+void jtk_launch_mark_pieces(const JtkWork& w, const int64_t* begin, const int64_t* end, int64_t n_pieces, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);

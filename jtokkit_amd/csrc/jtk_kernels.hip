@@ -89,11 +89,11 @@ __device__ int64_t find_doc(const JtkWork& w, int64_t p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// special_check: flag documents that contain a special-token literal (all literals start with "<|").
-// The exact test at one position; pretok_split calls it for the '<' bytes it sees.
+// special_check: flag documents that contain a special-token literal (GptBytePairEncoding.java:52-56: text.contains).
+// The exact test at one position; pretok_split calls it for the bytes it sees that some literal starts with.
 // ---------------------------------------------------------------------------------------------------
 __device__ void special_check_at(const JtkWork& w, const JtkDeviceTables& t, int64_t p) {
-    if (p < 0 || p + 1 >= w.n_bytes || w.text[p] != '<' || w.text[p + 1] != '|') return;
+    if (p < 0 || p >= w.n_bytes) return;
     for (int s = 0; s < t.n_specials; s++) {
         const int len = t.special_len[s];
         if (p + len > w.n_bytes) continue;
@@ -211,7 +211,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
     const int64_t n = w.n_bytes;
-    s_codes[tid] = (uint16_t)jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
+    {
+        uint32_t code = jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
+        for (int q = 0; q < t.n_specials; q++) if (t.special[q][0] == (uint8_t)tid) code |= JTK_F_LT;
+        s_codes[tid] = (uint16_t)code;
+    }
     if (tid == 0) s_uc_ready = 0;
     for (int i = tid; i < 2048; i += 256) s_pin[i] = t.pair_in_token[i];
     __syncthreads();
@@ -377,6 +381,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
     __shared__ uint16_t s_plist[T + 1];
     __shared__ uint64_t s_pm[TW];
+    __shared__ uint64_t s_gap[TW];
     __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
     __shared__ uint32_t s_qn[JTK_NBINS], s_qb[JTK_NBINS], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
@@ -402,6 +407,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         // a chunk of a larger batch starts at its first document, not at its first (tile-aligned) byte
         if (wd * 64 < w.lead) m &= (wd * 64 + 64 <= w.lead) ? 0ull : ~((1ull << (w.lead - wd * 64)) - 1ull);
         s_pm[tid] = m;
+        s_gap[tid] = (w.gapmask && wd < w.n_words) ? w.gapmask[wd] : 0ull;
     }
     if (tid < JTK_NBINS) s_qn[tid] = 0;
     if (tid == 0) s_nhard = 0;
@@ -434,6 +440,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     // (jtk_common.h): ONE scattered fetch per piece (two adjacent words for a 9..16-byte piece) answers hit or miss unless
     // the slot is flagged "overflowed"; only those lanes read their secondary slot in a second round.
     const int64_t next_after = s_next_after;
+    const bool gaps = w.gapmask != nullptr;
     const uint8_t* const t8 = reinterpret_cast<const uint8_t*>(t.tok8.slots);
     const uint8_t* const t16 = reinterpret_cast<const uint8_t*>(t.tok16.slots);
     uint32_t* const plist = w.plist + B;
@@ -496,7 +503,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int s = pr.s, len = pr.len;
         uint32_t entry = JTK_PL_HARD | JTK_PL_NOQUEUE | (uint32_t)s;
         int bin = -1;
-        if (len <= 16) {
+        if (gaps && ((s_gap[s >> 6] >> (s & 63)) & 1ull)) {
+            // text the caller's pattern did not match: no tokens (an htok header with count 0)
+            w.htok[B + s] = 0u;
+            atomicAdd(&s_nhard, 1u);
+        } else if (len <= 16) {
             if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT); else bin = 0;
         } else if (len <= 32) bin = 1;
         else if (len <= 64) bin = 2;
@@ -827,7 +838,10 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
             const uint32_t cc = have ? c : 0u;
             const uint32_t inc = wave_incl_scan(cc);
             const uint32_t tlo = (uint32_t)tile, thi = (uint32_t)((uint64_t)tile >> 32);
-            const bool head = lane == 0 || (uint32_t)__shfl_up((int)tlo, 1) != tlo || (uint32_t)__shfl_up((int)thi, 1) != thi;
+            // (the shuffles are evaluated by ALL lanes, outside the condition: a lane that short-circuits an `||` leaves the
+            // wave for the rest of the expression, and its neighbour would read a dead lane)
+            const uint32_t plo = (uint32_t)__shfl_up((int)tlo, 1), phi = (uint32_t)__shfl_up((int)thi, 1);
+            const bool head = lane == 0 || plo != tlo || phi != thi;
             const uint64_t heads = __ballot(head);
             const uint64_t later = heads & ~((2ull << lane) - 1ull);                  // run heads after this lane
             const int last = later ? jtk_ctz64(later) - 1 : 63;                        // last lane of this lane's run
@@ -1661,6 +1675,46 @@ void jtk_launch_stitch(const int64_t* totals, int rank, int64_t* base_out, const
                        hipStream_t s) {
     const int64_t n = global_off ? n_docs + 1 : 1;
     hipLaunchKernelGGL(k_stitch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, totals, rank, base_out, tok_off, n_docs, global_off);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Caller-supplied pieces (jtk_batch_encode_pieces): the host has run its own java.util.regex.Pattern
+// (api/GptBytePairEncodingParams.java:36-46, EncodingFactory.java:117-119) and hands over the matches.  A piece starts
+// at begin[i]; where it ends without the next one starting (text the pattern did not match: matcher.find() skips it),
+// a dead "gap piece" starts, marked in gapmask; document starts that no match begins at start gap pieces too.
+// piecemask and gapmask are zeroed before.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mark_pieces(JtkWork w, const int64_t* begin, const int64_t* end, int64_t n_pieces) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const int64_t p = begin[i] - w.text_base, e = end[i] - w.text_base;
+    if (p < w.lead || e <= p || e > w.n_bytes || (i + 1 < n_pieces && begin[i + 1] - w.text_base < e)) {
+        atomicMin(&w.result->worst_status, -1 /* JTK_ERR_INVALID_ARGUMENT */);
+        return;
+    }
+    atomicOr((unsigned long long*)&w.piecemask[p >> 6], 1ull << (p & 63));
+    const bool next_adjacent = (i + 1 < n_pieces) && (begin[i + 1] - w.text_base == e);
+    if (!next_adjacent && e < w.n_bytes) {
+        atomicOr((unsigned long long*)&w.piecemask[e >> 6], 1ull << (e & 63));
+        atomicOr((unsigned long long*)&w.gapmask[e >> 6], 1ull << (e & 63));
+    }
+}
+// after k_mark_pieces: every document start is a piece start (a gap piece unless a match begins there), and so is the
+// end sentinel
+__global__ void __launch_bounds__(256) k_mark_doc_gaps(JtkWork w) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > w.n_docs) return;
+    const int64_t q = w.doc_off[d] - w.text_base;
+    if (q < w.lead || q > w.n_bytes) return;
+    const uint64_t bit = 1ull << (q & 63);
+    const uint64_t old = atomicOr((unsigned long long*)&w.piecemask[q >> 6], bit);
+    if (!(old & bit) && q < w.n_bytes) atomicOr((unsigned long long*)&w.gapmask[q >> 6], bit);
+}
+void jtk_launch_mark_pieces(const JtkWork& w, const int64_t* begin, const int64_t* end, int64_t n_pieces, hipStream_t s) {
+    if (n_pieces > 0)
+        hipLaunchKernelGGL(k_mark_pieces, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, s, w, begin, end, n_pieces);
+    const int64_t n = w.n_docs + 1;
+    hipLaunchKernelGGL(k_mark_doc_gaps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w);
 }
 
 void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s) {

@@ -123,6 +123,20 @@ class Batch:
                                         flags, C.byref(nt)))
         return nt.value
 
+    def encode_pieces(self, text_u8, doc_off, piece_begin, piece_end, ordinary=True, to_host=False):
+        """jtk_batch_encode_pieces: the caller's own pattern has been matched on the host; piece i is
+        text[piece_begin[i]:piece_end[i]] (positions in the whole batch).  Returns the token total."""
+        text_u8 = np.ascontiguousarray(text_u8, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+        pb = np.ascontiguousarray(piece_begin, dtype=np.int64)
+        pe = np.ascontiguousarray(piece_end, dtype=np.int64)
+        nt = C.c_int64(0)
+        flags = (N.JTK_ENCODE_ORDINARY if ordinary else 0) | (N.JTK_ENCODE_TO_HOST if to_host else 0)
+        self._count_only = False
+        _check(N.lib().jtk_batch_encode_pieces(self._h, text_u8.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1,
+                                               pb.ctypes.data, pe.ctypes.data, len(pb), flags, C.byref(nt)))
+        return nt.value
+
     def host_result(self):
         """After encode_host(to_host=True): zero-copy numpy views of the batch's pinned result buffers (valid until the
         next encode on this batch)."""
@@ -235,7 +249,11 @@ class Batch:
 class HipEncoding:
     """GPU-backed `Encoding` (reference GptBytePairEncoding.java:18 is the class this replaces)."""
 
-    def __init__(self, name, pattern_kind, tiktoken_bytes, special_tokens, device=0):
+    def __init__(self, name, pattern_kind, tiktoken_bytes, special_tokens, device=0, host_pattern=None):
+        """host_pattern: a compiled pattern object with finditer() over str (e.g. the `regex` module with the Java
+        pattern's text) for encodings whose split pattern is neither of the two the device evaluates; the batch methods
+        then match on the host and encode the matches through jtk_batch_encode_pieces."""
+        self._host_pattern = host_pattern
         lits = [k.encode("utf-8") for k in special_tokens]
         arr = (C.c_char_p * max(len(lits), 1))(*lits)
         ids = (C.c_int32 * max(len(lits), 1))(*special_tokens.values())
@@ -344,8 +362,34 @@ class HipEncoding:
 
     def encode_batch_packed(self, text_u8, doc_off, ordinary=False, validate=False):
         b = self._b()
-        b.encode_host(text_u8, doc_off, ordinary, validate)
+        if self._host_pattern is not None:
+            pb, pe = self._match_on_host(text_u8, doc_off)
+            b.encode_pieces(text_u8, doc_off, pb, pe, ordinary)
+        else:
+            b.encode_host(text_u8, doc_off, ordinary, validate)
         return b.fetch()
+
+    def _match_on_host(self, text_u8, doc_off):
+        """while (matcher.find()) over every document (GptBytePairEncoding.java:77-80) -> byte ranges of the matches."""
+        raw = np.ascontiguousarray(text_u8, dtype=np.uint8).tobytes()
+        pb, pe = [], []
+        for d in range(len(doc_off) - 1):
+            lo, hi = int(doc_off[d]), int(doc_off[d + 1])
+            doc = raw[lo:hi].decode("utf-8")
+            # character index -> byte offset
+            pos = 0
+            ci = 0
+            for m in self._host_pattern.finditer(doc):
+                s, e = m.span()
+                if e == s:
+                    continue
+                pos += len(doc[ci:s].encode("utf-8"))
+                nb = len(doc[s:e].encode("utf-8"))
+                pb.append(lo + pos)
+                pe.append(lo + pos + nb)
+                pos += nb
+                ci = e
+        return np.array(pb, dtype=np.int64), np.array(pe, dtype=np.int64)
 
     def encode_batch_max_tokens(self, texts, max_tokens, ordinary=False):
         """List of str/bytes -> list of EncodingResult, as Encoding.encode(text, maxTokens) gives for each."""

@@ -50,16 +50,17 @@ def get_encoding(name, device=0):
         return enc
 
 
-def new_custom_encoding(name, pattern_kind, mergeable_ranks, special_tokens=None, device=0):
+def new_custom_encoding(name, pattern_kind, mergeable_ranks, special_tokens=None, device=0, host_pattern=None):
     """A custom byte-pair encoding on the device: what EncodingRegistry.registerGptBytePairEncoding(
     GptBytePairEncodingParams(name, pattern, mergeableRanks, specialTokens)) builds in the reference
     (api/GptBytePairEncodingParams.java:36-46, AbstractEncodingRegistry.java:64-66, EncodingFactory.java:117-119).
 
-    mergeable_ranks: {bytes: rank}.  pattern_kind: JTK_PATTERN_R50K or JTK_PATTERN_CL100K -- arbitrary
-    java.util.regex patterns are not supported.  The rank table must contain all 256 single bytes and reproduce
+    mergeable_ranks: {bytes: rank}.  pattern_kind: JTK_PATTERN_R50K or JTK_PATTERN_CL100K are evaluated on the device;
+    any other pattern: pass host_pattern (an object with finditer(), e.g. regex.compile(java_pattern_text)) -- the batch
+    methods then match on the host and encode the matches on the device (jtk_batch_encode_pieces).  The rank table must contain all 256 single bytes and reproduce
     each of its entries under bytePairMerge (any table trained by byte-pair merging does); otherwise the C ABI
     reports JTK_ERR_UNSUPPORTED_TABLE."""
     import base64
     lines = [base64.b64encode(k) + b" " + str(int(v)).encode() for k, v in sorted(mergeable_ranks.items(), key=lambda kv: kv[1])]
     data = b"\n".join(lines) + b"\n"
-    return HipEncoding(name, pattern_kind, data, dict(special_tokens or {}), device)
+    return HipEncoding(name, pattern_kind, data, dict(special_tokens or {}), device, host_pattern=host_pattern)

@@ -457,6 +457,29 @@ long jtko_split(void* h, const uint8_t* utf8, size_t len, int64_t* ends, size_t 
     return (long)k;
 }
 
+// encodeOrdinaryInternal (GptBytePairEncoding.java:77-87) with the matches of a caller-supplied pattern: match i is
+// utf8[begin[i], end[i]); text between matches is skipped as matcher.find() does.  Whole-piece lookup first (:81-83),
+// else bytePairMerge (:85-86).  Returns the token count.
+long jtko_encode_pieces(void* h, const uint8_t* utf8, const int64_t* begin, const int64_t* end, long n_pieces, int32_t* out, size_t cap) {
+    Oracle* o = (Oracle*)h;
+    size_t k = 0;
+    for (long i = 0; i < n_pieces; i++) {
+        std::string match((const char*)utf8 + begin[i], (size_t)(end[i] - begin[i]));      // :80
+        auto it = o->decodedToEncoded.find(match);
+        if (it != o->decodedToEncoded.end()) {                                              // :81-83
+            if (k >= cap) return ERR_CAPACITY;
+            out[k++] = it->second;
+        } else {                                                                            // :85-86
+            std::vector<int> toks;
+            long rc = bytePairMerge(*o, match, toks);
+            if (rc < 0) return rc;
+            if (k + toks.size() > cap) return ERR_CAPACITY;
+            for (int t : toks) out[k++] = t;
+        }
+    }
+    return (long)k;
+}
+
 // bytePairMerge of one piece (no whole-piece shortcut): GptBytePairEncoding.java:200-275
 long jtko_merge_piece(void* h, const uint8_t* piece, size_t len, int32_t* out, size_t cap) {
     Oracle* o = (Oracle*)h;

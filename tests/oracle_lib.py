@@ -57,6 +57,8 @@ def lib():
         L.jtko_split.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.jtko_merge_piece.restype = C.c_long
         L.jtko_merge_piece.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.jtko_encode_pieces.restype = C.c_long
+        L.jtko_encode_pieces.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_size_t]
         L.jtko_decode.restype = C.c_long
         L.jtko_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.jtko_encode_batch.restype = C.c_long
@@ -132,6 +134,16 @@ class OracleEncoding:
     def merge_piece(self, piece):
         out = np.empty(len(piece) + 1, dtype=np.int32)
         n = lib().jtko_merge_piece(self._h, piece, len(piece), out.ctypes.data, len(out))
+        if n < 0:
+            raise OracleError(n)
+        return out[:n].tolist()
+
+    def encode_pieces(self, text, begins, ends):
+        """The matches [begins[i], ends[i]) of a caller-supplied pattern over `text` (bytes) -> token list."""
+        b = np.ascontiguousarray(begins, dtype=np.int64)
+        e = np.ascontiguousarray(ends, dtype=np.int64)
+        out = np.empty(len(text) + 1, dtype=np.int32)
+        n = lib().jtko_encode_pieces(self._h, text, b.ctypes.data, e.ctypes.data, len(b), out.ctypes.data, len(out))
         if n < 0:
             raise OracleError(n)
         return out[:n].tolist()

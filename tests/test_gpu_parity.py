@@ -734,3 +734,51 @@ def test_per_call_methods_from_many_threads(jt):
     for x in th:
         x.join()
     assert not errors, errors[0]
+
+
+def test_custom_pattern_pieces_path(jt):
+    """Custom split patterns (api/GptBytePairEncodingParams.java:36-46): the caller matches on the host, the device does the
+    whole-piece shortcut, bytePairMerge and packing for the matches (jtk_batch_encode_pieces).  Patterns here leave gaps
+    (unmatched text is skipped as matcher.find() does), make pieces of hundreds of bytes, and match at document edges;
+    expected = the oracle's encodeOrdinaryInternal loop over the same matches."""
+    import regex
+    from jtokkit_amd import corpus, _native as N
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = corpus.mixed(300, mean_bytes=900, lo=64, hi=8192, seed=61)
+    docs = [text[doc_off[d]:doc_off[d + 1]].tobytes() for d in range(len(doc_off) - 1)] + [b"", b"   ", b"x", b"  lead and trail  "]
+    text2 = np.frombuffer(b"".join(docs), dtype=np.uint8).copy()
+    off2 = np.zeros(len(docs) + 1, dtype=np.int64)
+    np.cumsum([len(d) for d in docs], out=off2[1:])
+    for pat in (r"\w+|[^\w\s]+",                  # drops all whitespace: gaps everywhere
+                r"[^\n]+",                        # whole lines: pieces of hundreds of bytes
+                r"\p{L}{1,5}|\p{N}|\s+"):         # short letter chunks, single digits; punctuation is skipped
+        cp = regex.compile(pat)
+        henc = jt.HipEncoding.__new__(jt.HipEncoding)
+        henc._host_pattern = cp
+        pb, pe = jt.HipEncoding._match_on_host(henc, text2, off2)
+        b = enc.new_batch()
+        b.set_option(N.JTK_OPT_HOST_CHUNK_BYTES, 128 * 1024)          # several chunks
+        nt = b.encode_pieces(text2, off2, pb, pe)
+        res = b.fetch()
+        assert (res.status == 0).all() and nt == len(res.tokens) == res.tok_off[-1]
+        k = 0
+        for d, doc in enumerate(docs):
+            lo, hi = off2[d], off2[d + 1]
+            k0 = k
+            while k < len(pb) and pb[k] < hi:
+                k += 1
+            exp = o.encode_pieces(doc, pb[k0:k] - lo, pe[k0:k] - lo)
+            assert res.doc(d).tolist() == exp, (pat, d)
+        b.close()
+    # encode() (not encodeOrdinary): the special-token check still applies
+    b = enc.new_batch()
+    t = np.frombuffer(b"ok doc|has <|endoftext|> inside", dtype=np.uint8)
+    b.encode_pieces(t, np.array([0, 7, len(t)]), np.array([0, 3, 7, 11]), np.array([2, 6, 10, 24]), ordinary=False)
+    assert b.fetch().status.tolist() == [0, -2]
+    # malformed piece lists are refused
+    with pytest.raises(jt.EncodingError):
+        b.encode_pieces(t, np.array([0, 7, len(t)]), np.array([0, 5]), np.array([6, 9]))      # overlapping
+    with pytest.raises(jt.EncodingError):
+        b.encode_pieces(t, np.array([0, 7, len(t)]), np.array([5]), np.array([9]))            # crosses a document boundary
+    b.close()
