@@ -3,6 +3,10 @@
 // The reference is compiled (JVM) code and no JDK exists in the build image, so this class is the
 // host-side stand-in for the Java `HipEncoding implements Encoding` shown in INTEGRATION.md:
 // same method names, argument meaning and error behaviour (status codes become exceptions).
+// Like the Java shim, the per-call methods go through the encoding's jtk_service (thread-safe, concurrent callers
+// coalesced into device batches); the batch methods use the object's own jtk_batch (one caller at a time).
+// Compiled and run by the CPU test tier (tests/test_abi_and_host.py: no device -> IllegalStateException) and used by
+// tools/percall for nothing: it is the C++ face of the boundary, kept honest by that test.
 #ifndef JTK_ENCODING_HPP
 #define JTK_ENCODING_HPP
 
@@ -37,8 +41,9 @@ public:
         check(jtk_encoding_create(name.c_str(), patternKind, (const uint8_t*)tiktokenBytes.data(), tiktokenBytes.size(),
                                   lits.data(), ids.data(), (int)lits.size(), device, &enc_));
         check(jtk_batch_create(enc_, &batch_));
+        check(jtk_service_create(enc_, 2, &svc_));
     }
-    ~Encoding() { jtk_batch_destroy(batch_); jtk_encoding_destroy(enc_); }
+    ~Encoding() { jtk_service_destroy(svc_); jtk_batch_destroy(batch_); jtk_encoding_destroy(enc_); }
     Encoding(const Encoding&) = delete;
     Encoding& operator=(const Encoding&) = delete;
 
@@ -68,6 +73,19 @@ public:
         check(jtk_batch_fetch(batch_, tokens.data(), nt, tokOff.data(), status.data()));
     }
 
+    // custom split pattern: the caller's matches (byte ranges in the whole batch) instead of the device's split
+    // (api/GptBytePairEncodingParams.java:36-46); text between matches is skipped as matcher.find() does
+    void encodeBatchPieces(const uint8_t* utf8, const std::vector<int64_t>& docOff, const std::vector<int64_t>& pieceBegin,
+                           const std::vector<int64_t>& pieceEnd, bool ordinary, std::vector<int32_t>& tokens,
+                           std::vector<int64_t>& tokOff, std::vector<int32_t>& status) {
+        int64_t nt = 0;
+        const int64_t n = (int64_t)docOff.size() - 1;
+        check(jtk_batch_encode_pieces(batch_, utf8, docOff.data(), n, pieceBegin.data(), pieceEnd.data(), (int64_t)pieceBegin.size(),
+                                      ordinary ? JTK_ENCODE_ORDINARY : 0u, &nt));
+        tokens.resize((size_t)nt); tokOff.resize((size_t)n + 1); status.resize((size_t)n);
+        check(jtk_batch_fetch(batch_, tokens.data(), nt, tokOff.data(), status.data()));
+    }
+
     // batch encode(text, maxTokens): after encodeBatch, how many of each document's tokens survive the limit (incl. the
     // reference's back-off to a code-point boundary) and EncodingResult.isTruncated() per document
     void truncateBatch(int64_t maxTokens, std::vector<int64_t>& kept, std::vector<uint8_t>& truncated, size_t nDocs) {
@@ -90,8 +108,8 @@ private:
     EncodingResult run(const std::string& text, uint32_t flags, int64_t maxTokens) {
         EncodingResult r{std::vector<int32_t>(text.size() + 1), false};
         int64_t n = 0; int tr = 0;
-        check(jtk_encode(batch_, (const uint8_t*)text.data(), (int64_t)text.size(), flags, maxTokens, r.tokens.data(),
-                         (int64_t)r.tokens.size(), &n, &tr));
+        check(jtk_service_encode(svc_, (const uint8_t*)text.data(), (int64_t)text.size(), flags, maxTokens, r.tokens.data(),
+                                 (int64_t)r.tokens.size(), &n, &tr));
         r.tokens.resize((size_t)n);
         r.truncated = tr != 0;
         return r;
@@ -105,6 +123,7 @@ private:
     }
     jtk_encoding* enc_ = nullptr;
     jtk_batch* batch_ = nullptr;
+    jtk_service* svc_ = nullptr;
 };
 
 }  // namespace jtokkit

@@ -33,14 +33,56 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 
 	private final String name;
 	private final long encodingHandle;
-	/** jtk_batch is single-threaded; Encoding must be thread-safe (EncodingRegistry.java:51,61). */
-	private final ThreadLocal<Long> batch;
+	/**
+	 * Encoding must be thread-safe (EncodingRegistry.java:51,61).  The per-call methods go through ONE jtk_service per
+	 * encoding: it is thread-safe and coalesces concurrent callers into device batches.  The batch methods use a
+	 * jtk_batch (one caller at a time) taken from a small pool; every batch ever created is tracked so that close()
+	 * can destroy them before the encoding.
+	 */
+	private final long serviceHandle;
+	private final java.util.concurrent.ConcurrentLinkedQueue<Long> idleBatches = new java.util.concurrent.ConcurrentLinkedQueue<>();
+	private final java.util.Set<Long> allBatches = java.util.concurrent.ConcurrentHashMap.newKeySet();
+	private final java.util.regex.Pattern hostPattern;   // null: one of the two patterns the device evaluates
+	private volatile boolean closed;
+
+	private HipEncoding(final String name, final int patternKind, final byte[] tiktoken,
+			final String[] specialLiterals, final int[] specialIds, final int device, final java.util.regex.Pattern hostPattern) {
+		this.name = name;
+		this.hostPattern = hostPattern;
+		this.encodingHandle = nativeCreate(name, patternKind, tiktoken, specialLiterals, specialIds, device);
+		this.serviceHandle = nativeServiceCreate(encodingHandle, 2);
+	}
 
 	private HipEncoding(final String name, final int patternKind, final byte[] tiktoken,
 			final String[] specialLiterals, final int[] specialIds, final int device) {
-		this.name = name;
-		this.encodingHandle = nativeCreate(name, patternKind, tiktoken, specialLiterals, specialIds, device);
-		this.batch = ThreadLocal.withInitial(() -> nativeBatchCreate(encodingHandle));
+		this(name, patternKind, tiktoken, specialLiterals, specialIds, device, null);
+	}
+
+	/**
+	 * A custom encoding (GptBytePairEncodingParams: name, pattern, mergeable ranks, special tokens) on the device.
+	 * Its pattern is matched here on the JVM (java.util.regex, exactly as the reference does) and only the matches go to
+	 * the device (jtk_batch_encode_pieces): whole-piece lookup, bytePairMerge and packing.
+	 */
+	public static HipEncoding custom(final String name, final java.util.regex.Pattern pattern, final byte[] tiktokenFileBytes,
+			final String[] specialLiterals, final int[] specialIds, final int device) {
+		return new HipEncoding(name, 1, tiktokenFileBytes, specialLiterals, specialIds, device, pattern);
+	}
+
+	private long borrowBatch() {
+		if (closed) {
+			throw new IllegalStateException("encoding is closed");
+		}
+		final Long b = idleBatches.poll();
+		if (b != null) {
+			return b;
+		}
+		final long created = nativeBatchCreate(encodingHandle);
+		allBatches.add(created);
+		return created;
+	}
+
+	private void returnBatch(final long b) {
+		idleBatches.add(b);
 	}
 
 	public static HipEncoding cl100kBase(final int device) {
@@ -123,7 +165,10 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 		final byte[] utf8 = text.getBytes(StandardCharsets.UTF_8);
 		final boolean[] truncated = new boolean[1];
 		// JTK_ERR_UNSUPPORTED_SPECIAL -> UnsupportedOperationException (thrown by the glue)
-		final int[] ids = nativeEncode(batch.get(), utf8, flags, maxTokens, truncated);
+		if (hostPattern != null) {
+			return encodeBatchPieces(Collections.singletonList(text), (flags & 1) != 0, maxTokens).get(0);
+		}
+		final int[] ids = nativeServiceEncode(serviceHandle, utf8, flags, maxTokens, truncated);
 		final List<Integer> out = new ArrayList<>(ids.length);
 		for (final int id : ids) {
 			out.add(id);
@@ -135,15 +180,139 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 
 	/**
 	 * Encodes all documents in one device pass.  {@code utf8} holds the documents' UTF-8 bytes back to
-	 * back (direct buffer), {@code docOff} n+1 offsets; returns packed ids plus n+1 token offsets.
+	 * back (direct buffer; best allocated by {@link #allocatePinned(long)}), {@code docOff} n+1 offsets; returns packed ids
+	 * plus n+1 token offsets.
 	 */
 	public BatchResult encodeBatch(final ByteBuffer utf8, final long[] docOff, final boolean ordinary) {
-		return nativeEncodeBatch(batch.get(), utf8, docOff, ordinary ? 1 : 0);
+		final long b = borrowBatch();
+		try {
+			return nativeEncodeBatch(b, utf8, docOff, ordinary ? 1 : 0);
+		} finally {
+			returnBatch(b);
+		}
 	}
 
 	public BatchResult encodeBatch(final List<String> texts, final boolean ordinary) {
-		final byte[][] bs = new byte[texts.size()][];
 		final long[] off = new long[texts.size() + 1];
+		final ByteBuffer buf = pack(texts, off);
+		return encodeBatch(buf, off, ordinary);
+	}
+
+	/** Encoding.countTokens / countTokensOrdinary for every text, one device pass, no token ids copied back. */
+	public int[] countTokensBatch(final List<String> texts, final boolean ordinary) {
+		final long[] off = new long[texts.size() + 1];
+		final ByteBuffer buf = pack(texts, off);
+		final long b = borrowBatch();
+		try {
+			final BatchResult r = nativeEncodeBatch(b, buf, off, (ordinary ? 1 : 0) | 4 /* JTK_ENCODE_COUNT_ONLY */);
+			final int[] counts = new int[texts.size()];
+			for (int d = 0; d < counts.length; d++) {
+				throwForStatus(r.status[d]);
+				counts[d] = (int) (r.tokOff[d + 1] - r.tokOff[d]);
+			}
+			return counts;
+		} finally {
+			returnBatch(b);
+		}
+	}
+
+	/** Encoding.encode(text, maxTokens) / encodeOrdinary(text, maxTokens) for every text: one encode pass + jtk_batch_truncate. */
+	public List<EncodingResult> encodeBatch(final List<String> texts, final boolean ordinary, final int maxTokens) {
+		if (hostPattern != null) {
+			return encodeBatchPieces(texts, ordinary, maxTokens);
+		}
+		final long[] off = new long[texts.size() + 1];
+		final ByteBuffer buf = pack(texts, off);
+		final long b = borrowBatch();
+		try {
+			final BatchResult r = nativeEncodeBatch(b, buf, off, ordinary ? 1 : 0);
+			final long[] kept = new long[texts.size()];
+			final boolean[] truncated = new boolean[texts.size()];
+			nativeTruncateBatch(b, maxTokens, kept, truncated);            // GptBytePairEncoding.java:90-100 on the device
+			return toResults(r, kept, truncated);
+		} finally {
+			returnBatch(b);
+		}
+	}
+
+	/** Encoding.decodeBytes for many token lists in one device pass (special-token ids decode to their literals). */
+	public List<byte[]> decodeBytesBatch(final List<List<Integer>> tokenLists) {
+		final long[] seqOff = new long[tokenLists.size() + 1];
+		for (int q = 0; q < tokenLists.size(); q++) {
+			seqOff[q + 1] = seqOff[q] + tokenLists.get(q).size();
+		}
+		final int[] ids = new int[(int) seqOff[tokenLists.size()]];
+		int k = 0;
+		for (final List<Integer> l : tokenLists) {
+			for (final int id : l) {
+				ids[k++] = id;
+			}
+		}
+		final long b = borrowBatch();
+		try {
+			return java.util.Arrays.asList(nativeDecodeBatch(b, ids, seqOff));   // JTK_ERR_UNKNOWN_TOKEN -> IllegalArgumentException
+		} finally {
+			returnBatch(b);
+		}
+	}
+
+	/**
+	 * Custom patterns: {@code while (matcher.find())} (GptBytePairEncoding.java:77-80) runs here, its matches go to the
+	 * device as byte ranges.  Text between matches is skipped, as in the reference.
+	 */
+	private List<EncodingResult> encodeBatchPieces(final List<String> texts, final boolean ordinary, final int maxTokens) {
+		final long[] off = new long[texts.size() + 1];
+		final ByteBuffer buf = pack(texts, off);
+		final java.util.ArrayList<Long> begin = new java.util.ArrayList<>();
+		final java.util.ArrayList<Long> end = new java.util.ArrayList<>();
+		for (int d = 0; d < texts.size(); d++) {
+			final String text = texts.get(d) == null ? "" : texts.get(d);
+			final java.util.regex.Matcher m = hostPattern.matcher(text);
+			long bytePos = off[d];
+			int charPos = 0;
+			while (m.find()) {
+				if (m.end() == m.start()) {
+					continue;
+				}
+				bytePos += text.substring(charPos, m.start()).getBytes(StandardCharsets.UTF_8).length;
+				final long len = m.group().getBytes(StandardCharsets.UTF_8).length;
+				begin.add(bytePos);
+				end.add(bytePos + len);
+				bytePos += len;
+				charPos = m.end();
+			}
+		}
+		final long[] pb = begin.stream().mapToLong(Long::longValue).toArray();
+		final long[] pe = end.stream().mapToLong(Long::longValue).toArray();
+		final long b = borrowBatch();
+		try {
+			final BatchResult r = nativeEncodeBatchPieces(b, buf, off, pb, pe, ordinary ? 1 : 0);
+			final long[] kept = new long[texts.size()];
+			final boolean[] truncated = new boolean[texts.size()];
+			if (maxTokens >= 0) {
+				nativeTruncateBatch(b, maxTokens, kept, truncated);
+			} else {
+				for (int d = 0; d < kept.length; d++) {
+					kept[d] = r.tokOff[d + 1] - r.tokOff[d];
+				}
+			}
+			return toResults(r, kept, truncated);
+		} finally {
+			returnBatch(b);
+		}
+	}
+
+	/** A direct buffer in page-locked memory (jtk_host_alloc): the device reads it by DMA.  Free with {@link #freePinned}. */
+	public static ByteBuffer allocatePinned(final long bytes) {
+		return nativeHostAlloc(bytes).order(ByteOrder.nativeOrder());
+	}
+
+	public static void freePinned(final ByteBuffer buffer) {
+		nativeHostFree(buffer);
+	}
+
+	private static ByteBuffer pack(final List<String> texts, final long[] off) {
+		final byte[][] bs = new byte[texts.size()][];
 		for (int i = 0; i < bs.length; i++) {
 			bs[i] = texts.get(i) == null ? new byte[0] : texts.get(i).getBytes(StandardCharsets.UTF_8);
 			off[i + 1] = off[i] + bs[i].length;
@@ -153,7 +322,29 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 			buf.put(b);
 		}
 		buf.flip();
-		return encodeBatch(buf, off, ordinary);
+		return buf;
+	}
+
+	private static List<EncodingResult> toResults(final BatchResult r, final long[] kept, final boolean[] truncated) {
+		final List<EncodingResult> out = new ArrayList<>(kept.length);
+		for (int d = 0; d < kept.length; d++) {
+			throwForStatus(r.status[d]);
+			final List<Integer> ids = new ArrayList<>((int) kept[d]);
+			for (long k = r.tokOff[d]; k < r.tokOff[d] + kept[d]; k++) {
+				ids.add(r.tokens[(int) k]);
+			}
+			out.add(new EncodingResult(ids, truncated[d]));
+		}
+		return out;
+	}
+
+	private static void throwForStatus(final int status) {
+		if (status == -2) {
+			throw new UnsupportedOperationException("Encoding special tokens is not supported yet.");   // GptBytePairEncoding.java:54
+		}
+		if (status != 0) {
+			throw new IllegalStateException("document could not be encoded: jtk_status " + status);
+		}
 	}
 
 	/** Packed result of a batch: ids of document d are tokens[tokOff[d] .. tokOff[d+1]); status[d] != 0 = error. */
@@ -169,18 +360,38 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 		}
 	}
 
+	/** Service first (its workers own batches of their own), then every batch this object created, then the encoding. */
 	@Override
-	public void close() {
+	public synchronized void close() {
+		if (closed) {
+			return;
+		}
+		closed = true;
+		nativeServiceDestroy(serviceHandle);
+		for (final long b : allBatches) {
+			nativeBatchDestroy(b);
+		}
+		allBatches.clear();
+		idleBatches.clear();
 		nativeDestroy(encodingHandle);
 	}
 
 	private static native long nativeCreate(String name, int patternKind, byte[] tiktoken, String[] specialLiterals,
 			int[] specialIds, int device);
 	private static native void nativeDestroy(long encoding);
+	private static native long nativeServiceCreate(long encoding, int workers);
+	private static native void nativeServiceDestroy(long service);
+	private static native int[] nativeServiceEncode(long service, byte[] utf8, int flags, int maxTokens, boolean[] truncated);
 	private static native long nativeBatchCreate(long encoding);
-	private static native int[] nativeEncode(long batch, byte[] utf8, int flags, int maxTokens, boolean[] truncated);
+	private static native void nativeBatchDestroy(long batch);
 	private static native BatchResult nativeEncodeBatch(long batch, ByteBuffer utf8, long[] docOff, int flags);
+	private static native BatchResult nativeEncodeBatchPieces(long batch, ByteBuffer utf8, long[] docOff, long[] pieceBegin,
+			long[] pieceEnd, int flags);
+	private static native void nativeTruncateBatch(long batch, long maxTokens, long[] kept, boolean[] truncated);
+	private static native byte[][] nativeDecodeBatch(long batch, int[] ids, long[] seqOff);
 	private static native byte[] nativeDecode(long encoding, int[] ids);
+	private static native ByteBuffer nativeHostAlloc(long bytes);
+	private static native void nativeHostFree(ByteBuffer buffer);
 
 	private static final class Resources {
 		static byte[] read(final String path) {

@@ -2,7 +2,10 @@
  * NOT COMPILED in the build image (no JDK / jni.h there).  Build where a JDK exists:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include jtk_jni.c \
  *       -L.. -ljtokkit_amd -o libjtokkit_amd_jni.so
- * Status codes map 1:1 to the exceptions the reference throws (see the enum in jtokkit_amd.h). */
+ * Status codes map 1:1 to the exceptions the reference throws (see the enum in jtokkit_amd.h).
+ * No JNI critical section is held across a device call (a blocking HIP call inside GetPrimitiveArrayCritical can stall the
+ * collector): results are read from the batch's pinned host buffers (JTK_ENCODE_TO_HOST + jtk_batch_host_result) and
+ * copied with Set*ArrayRegion. */
 #include <jni.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,24 +23,37 @@ static void throw_for(JNIEnv* env, int rc) {
         case JTK_ERR_OUT_OF_MEMORY: cls = "java/lang/OutOfMemoryError"; break;
         default: cls = "java/lang/IllegalStateException"; break;                  /* EncodingFactory.java:142,151,162 */
     }
-    (*env)->ThrowNew(env, (*env)->FindClass(env, cls), msg);
+    jclass c = (*env)->FindClass(env, cls);
+    (*env)->ThrowNew(env, c, msg);
+    (*env)->DeleteLocalRef(env, c);
 }
 
-JNIEXPORT jlong JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeCreate(
-        JNIEnv* env, jclass c, jstring name, jint kind, jbyteArray tiktoken, jobjectArray lits, jintArray ids, jint device) {
+#define ENC(h) ((jtk_encoding*)(intptr_t)(h))
+#define BATCH(h) ((jtk_batch*)(intptr_t)(h))
+#define SVC(h) ((jtk_service*)(intptr_t)(h))
+#define FN(name) Java_com_knuddels_jtokkit_hip_HipEncoding_##name
+
+JNIEXPORT jlong JNICALL FN(nativeCreate)(JNIEnv* env, jclass c, jstring name, jint kind, jbyteArray tiktoken, jobjectArray lits,
+                                         jintArray ids, jint device) {
     (void)c;
     const char* cname = (*env)->GetStringUTFChars(env, name, NULL);   /* ASCII encoding name only */
     jsize tlen = (*env)->GetArrayLength(env, tiktoken);
     jbyte* tbytes = (*env)->GetByteArrayElements(env, tiktoken, NULL);
     jsize ns = (*env)->GetArrayLength(env, lits);
     const char** clits = (const char**)calloc((size_t)ns + 1, sizeof(char*));
+    jstring* jlits = (jstring*)calloc((size_t)ns + 1, sizeof(jstring));          /* the elements are fetched ONCE and kept */
     jint* cids = (*env)->GetIntArrayElements(env, ids, NULL);
-    for (jsize i = 0; i < ns; i++)
-        clits[i] = (*env)->GetStringUTFChars(env, (jstring)(*env)->GetObjectArrayElement(env, lits, i), NULL);
+    for (jsize i = 0; i < ns; i++) {
+        jlits[i] = (jstring)(*env)->GetObjectArrayElement(env, lits, i);
+        clits[i] = (*env)->GetStringUTFChars(env, jlits[i], NULL);               /* special literals are ASCII */
+    }
     jtk_encoding* enc = NULL;
     int rc = jtk_encoding_create(cname, kind, (const uint8_t*)tbytes, (size_t)tlen, clits, (const int32_t*)cids, ns, device, &enc);
-    for (jsize i = 0; i < ns; i++)
-        (*env)->ReleaseStringUTFChars(env, (jstring)(*env)->GetObjectArrayElement(env, lits, i), clits[i]);
+    for (jsize i = 0; i < ns; i++) {
+        (*env)->ReleaseStringUTFChars(env, jlits[i], clits[i]);
+        (*env)->DeleteLocalRef(env, jlits[i]);
+    }
+    free(jlits);
     free(clits);
     (*env)->ReleaseIntArrayElements(env, ids, cids, JNI_ABORT);
     (*env)->ReleaseByteArrayElements(env, tiktoken, tbytes, JNI_ABORT);
@@ -46,28 +62,27 @@ JNIEXPORT jlong JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeCreate(
     return (jlong)(intptr_t)enc;
 }
 
-JNIEXPORT void JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeDestroy(JNIEnv* env, jclass c, jlong h) {
-    (void)env; (void)c;
-    jtk_encoding_destroy((jtk_encoding*)(intptr_t)h);
-}
+JNIEXPORT void JNICALL FN(nativeDestroy)(JNIEnv* env, jclass c, jlong h) { (void)env; (void)c; jtk_encoding_destroy(ENC(h)); }
 
-JNIEXPORT jlong JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeBatchCreate(JNIEnv* env, jclass c, jlong h) {
+JNIEXPORT jlong JNICALL FN(nativeServiceCreate)(JNIEnv* env, jclass c, jlong h, jint workers) {
     (void)c;
-    jtk_batch* b = NULL;
-    int rc = jtk_batch_create((const jtk_encoding*)(intptr_t)h, &b);
+    jtk_service* s = NULL;
+    int rc = jtk_service_create(ENC(h), workers, &s);
     if (rc != JTK_OK) { throw_for(env, rc); return 0; }
-    return (jlong)(intptr_t)b;
+    return (jlong)(intptr_t)s;
 }
+JNIEXPORT void JNICALL FN(nativeServiceDestroy)(JNIEnv* env, jclass c, jlong s) { (void)env; (void)c; jtk_service_destroy(SVC(s)); }
 
-JNIEXPORT jintArray JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeEncode(
-        JNIEnv* env, jclass c, jlong batch, jbyteArray utf8, jint flags, jint maxTokens, jbooleanArray truncated) {
+/* Encoding.encode / encodeOrdinary (with or without maxTokens) for one String: blocks in the service, which coalesces the
+ * concurrent callers into one device batch */
+JNIEXPORT jintArray JNICALL FN(nativeServiceEncode)(JNIEnv* env, jclass c, jlong svc, jbyteArray utf8, jint flags, jint maxTokens,
+                                                    jbooleanArray truncated) {
     (void)c;
     jsize len = (*env)->GetArrayLength(env, utf8);
     jbyte* bytes = (*env)->GetByteArrayElements(env, utf8, NULL);
     int32_t* toks = (int32_t*)malloc(((size_t)len + 1) * sizeof(int32_t));     /* tokens <= bytes */
     int64_t n = 0; int tr = 0;
-    int rc = jtk_encode((jtk_batch*)(intptr_t)batch, (const uint8_t*)bytes, len, (uint32_t)flags, maxTokens,
-                        toks, (int64_t)len + 1, &n, &tr);
+    int rc = jtk_service_encode(SVC(svc), (const uint8_t*)bytes, len, (uint32_t)flags, maxTokens, toks, (int64_t)len + 1, &n, &tr);
     (*env)->ReleaseByteArrayElements(env, utf8, bytes, JNI_ABORT);
     if (rc != JTK_OK) { free(toks); throw_for(env, rc); return NULL; }
     jintArray out = (*env)->NewIntArray(env, (jsize)n);
@@ -78,45 +93,143 @@ JNIEXPORT jintArray JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeEnco
     return out;
 }
 
-JNIEXPORT jobject JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeEncodeBatch(
-        JNIEnv* env, jclass c, jlong batch, jobject utf8, jlongArray docOff, jint flags) {
+JNIEXPORT jlong JNICALL FN(nativeBatchCreate)(JNIEnv* env, jclass c, jlong h) {
     (void)c;
-    jtk_batch* b = (jtk_batch*)(intptr_t)batch;
-    const uint8_t* text = (const uint8_t*)(*env)->GetDirectBufferAddress(env, utf8);
-    jsize n1 = (*env)->GetArrayLength(env, docOff);
-    jlong* off = (*env)->GetLongArrayElements(env, docOff, NULL);
+    jtk_batch* b = NULL;
+    int rc = jtk_batch_create(ENC(h), &b);
+    if (rc != JTK_OK) { throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)b;
+}
+JNIEXPORT void JNICALL FN(nativeBatchDestroy)(JNIEnv* env, jclass c, jlong b) { (void)env; (void)c; jtk_batch_destroy(BATCH(b)); }
+
+/* the batch's pinned host result -> HipEncoding.BatchResult(int[] tokens, long[] tokOff, int[] status) */
+static jobject batch_result(JNIEnv* env, jtk_batch* b, jsize n_docs) {
+    const int32_t* toks = NULL; const int64_t* toff = NULL; const int32_t* stat = NULL;
     int64_t nt = 0;
-    int rc = jtk_batch_encode(b, text, (const int64_t*)off, n1 - 1, (uint32_t)flags, &nt);
-    (*env)->ReleaseLongArrayElements(env, docOff, off, JNI_ABORT);
+    int rc = jtk_batch_result(b, &nt, NULL, NULL);
+    if (rc == JTK_OK) rc = jtk_batch_host_result(b, &toks, &toff, &stat);
     if (rc != JTK_OK) { throw_for(env, rc); return NULL; }
-    jintArray toks = (*env)->NewIntArray(env, (jsize)nt);
-    jlongArray toff = (*env)->NewLongArray(env, n1);
-    jintArray stat = (*env)->NewIntArray(env, n1 - 1);
-    jint* ptoks = (*env)->GetPrimitiveArrayCritical(env, toks, NULL);
-    jlong* ptoff = (*env)->GetPrimitiveArrayCritical(env, toff, NULL);
-    jint* pstat = (*env)->GetPrimitiveArrayCritical(env, stat, NULL);
-    rc = jtk_batch_fetch(b, (int32_t*)ptoks, nt, (int64_t*)ptoff, (int32_t*)pstat);
-    (*env)->ReleasePrimitiveArrayCritical(env, stat, pstat, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, toff, ptoff, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, toks, ptoks, 0);
-    if (rc != JTK_OK) { throw_for(env, rc); return NULL; }
-    jclass rcCls = (*env)->FindClass(env, "com/knuddels/jtokkit/hip/HipEncoding$BatchResult");
-    jmethodID ctor = (*env)->GetMethodID(env, rcCls, "<init>", "([I[J[I)V");
-    return (*env)->NewObject(env, rcCls, ctor, toks, toff, stat);
+    jintArray jt = (*env)->NewIntArray(env, toks ? (jsize)nt : 0);
+    jlongArray jo = (*env)->NewLongArray(env, n_docs + 1);
+    jintArray js = (*env)->NewIntArray(env, n_docs);
+    if (toks && nt > 0) (*env)->SetIntArrayRegion(env, jt, 0, (jsize)nt, (const jint*)toks);
+    (*env)->SetLongArrayRegion(env, jo, 0, n_docs + 1, (const jlong*)toff);
+    if (n_docs > 0) (*env)->SetIntArrayRegion(env, js, 0, n_docs, (const jint*)stat);
+    jclass cls = (*env)->FindClass(env, "com/knuddels/jtokkit/hip/HipEncoding$BatchResult");
+    jmethodID ctor = (*env)->GetMethodID(env, cls, "<init>", "([I[J[I)V");
+    jobject out = (*env)->NewObject(env, cls, ctor, jt, jo, js);
+    (*env)->DeleteLocalRef(env, cls);
+    return out;
 }
 
-JNIEXPORT jbyteArray JNICALL Java_com_knuddels_jtokkit_hip_HipEncoding_nativeDecode(JNIEnv* env, jclass c, jlong h, jintArray ids) {
+/* a loop of Encoding.encode / encodeOrdinary / countTokens (flags bit 2) over a batch: chunked H2D, kernels and D2H overlap */
+JNIEXPORT jobject JNICALL FN(nativeEncodeBatch)(JNIEnv* env, jclass c, jlong batch, jobject utf8, jlongArray docOff, jint flags) {
+    (void)c;
+    const uint8_t* text = (const uint8_t*)(*env)->GetDirectBufferAddress(env, utf8);
+    jsize n1 = (*env)->GetArrayLength(env, docOff);
+    jlong* off = (*env)->GetLongArrayElements(env, docOff, NULL);                /* a copy or a pin, no critical section */
+    int64_t nt = 0;
+    int rc = jtk_batch_encode(BATCH(batch), text, (const int64_t*)off, n1 - 1, (uint32_t)flags | JTK_ENCODE_TO_HOST, &nt);
+    (*env)->ReleaseLongArrayElements(env, docOff, off, JNI_ABORT);
+    if (rc != JTK_OK) { throw_for(env, rc); return NULL; }
+    return batch_result(env, BATCH(batch), n1 - 1);
+}
+
+/* custom java.util.regex.Pattern: the matches found on the JVM, encoded on the device */
+JNIEXPORT jobject JNICALL FN(nativeEncodeBatchPieces)(JNIEnv* env, jclass c, jlong batch, jobject utf8, jlongArray docOff,
+                                                      jlongArray pieceBegin, jlongArray pieceEnd, jint flags) {
+    (void)c;
+    const uint8_t* text = (const uint8_t*)(*env)->GetDirectBufferAddress(env, utf8);
+    jsize n1 = (*env)->GetArrayLength(env, docOff), np = (*env)->GetArrayLength(env, pieceBegin);
+    jlong* off = (*env)->GetLongArrayElements(env, docOff, NULL);
+    jlong* pb = (*env)->GetLongArrayElements(env, pieceBegin, NULL);
+    jlong* pe = (*env)->GetLongArrayElements(env, pieceEnd, NULL);
+    int64_t nt = 0;
+    int rc = jtk_batch_encode_pieces(BATCH(batch), text, (const int64_t*)off, n1 - 1, (const int64_t*)pb, (const int64_t*)pe, np,
+                                     (uint32_t)flags | JTK_ENCODE_TO_HOST, &nt);
+    (*env)->ReleaseLongArrayElements(env, pieceEnd, pe, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, pieceBegin, pb, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, docOff, off, JNI_ABORT);
+    if (rc != JTK_OK) { throw_for(env, rc); return NULL; }
+    return batch_result(env, BATCH(batch), n1 - 1);
+}
+
+/* Encoding.encode(text, maxTokens) for every document of the batch's last encode (GptBytePairEncoding.java:90-100 on the device) */
+JNIEXPORT void JNICALL FN(nativeTruncateBatch)(JNIEnv* env, jclass c, jlong batch, jlong maxTokens, jlongArray kept, jbooleanArray truncated) {
+    (void)c;
+    jsize n = (*env)->GetArrayLength(env, kept);
+    int rc = jtk_batch_truncate(BATCH(batch), maxTokens);
+    int64_t* k = (int64_t*)malloc(((size_t)n + 1) * sizeof(int64_t));
+    uint8_t* t = (uint8_t*)malloc((size_t)n + 1);
+    if (rc == JTK_OK) rc = jtk_batch_fetch_truncated(BATCH(batch), k, t);
+    if (rc == JTK_OK) {
+        (*env)->SetLongArrayRegion(env, kept, 0, n, (const jlong*)k);
+        (*env)->SetBooleanArrayRegion(env, truncated, 0, n, (const jboolean*)t);
+    }
+    free(k); free(t);
+    if (rc != JTK_OK) throw_for(env, rc);
+}
+
+/* a loop of Encoding.decodeBytes over many token lists: one device pass */
+JNIEXPORT jobjectArray JNICALL FN(nativeDecodeBatch)(JNIEnv* env, jclass c, jlong batch, jintArray ids, jlongArray seqOff) {
+    (void)c;
+    jsize n1 = (*env)->GetArrayLength(env, seqOff);
+    jint* pid = (*env)->GetIntArrayElements(env, ids, NULL);
+    jlong* poff = (*env)->GetLongArrayElements(env, seqOff, NULL);
+    int64_t nb = 0;
+    int rc = jtk_batch_decode(BATCH(batch), (const int32_t*)pid, (const int64_t*)poff, n1 - 1, &nb);
+    (*env)->ReleaseLongArrayElements(env, seqOff, poff, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, ids, pid, JNI_ABORT);
+    if (rc != JTK_OK) { throw_for(env, rc); return NULL; }
+    uint8_t* bytes = (uint8_t*)malloc((size_t)nb + 1);
+    int64_t* boff = (int64_t*)malloc((size_t)n1 * sizeof(int64_t));
+    int32_t* stat = (int32_t*)malloc((size_t)n1 * sizeof(int32_t));
+    rc = jtk_batch_decode_fetch(BATCH(batch), bytes, nb, boff, stat);
+    jobjectArray out = NULL;
+    if (rc == JTK_OK) {
+        for (jsize q = 0; q + 1 < n1 && rc == JTK_OK; q++) if (stat[q] != JTK_OK) rc = stat[q];     /* :313 unknown token */
+    }
+    if (rc == JTK_OK) {
+        jclass ba = (*env)->FindClass(env, "[B");
+        out = (*env)->NewObjectArray(env, n1 - 1, ba, NULL);
+        for (jsize q = 0; q + 1 < n1; q++) {
+            jbyteArray one = (*env)->NewByteArray(env, (jsize)(boff[q + 1] - boff[q]));
+            (*env)->SetByteArrayRegion(env, one, 0, (jsize)(boff[q + 1] - boff[q]), (const jbyte*)(bytes + boff[q]));
+            (*env)->SetObjectArrayElement(env, out, q, one);
+            (*env)->DeleteLocalRef(env, one);
+        }
+        (*env)->DeleteLocalRef(env, ba);
+    }
+    free(bytes); free(boff); free(stat);
+    if (rc != JTK_OK) { throw_for(env, rc); return NULL; }
+    return out;
+}
+
+JNIEXPORT jbyteArray JNICALL FN(nativeDecode)(JNIEnv* env, jclass c, jlong h, jintArray ids) {
     (void)c;
     jsize n = (*env)->GetArrayLength(env, ids);
     jint* p = (*env)->GetIntArrayElements(env, ids, NULL);
     int64_t len = 0;
-    int rc = jtk_decode((const jtk_encoding*)(intptr_t)h, (const int32_t*)p, n, NULL, 0, &len);
+    int rc = jtk_decode(ENC(h), (const int32_t*)p, n, NULL, 0, &len);
     uint8_t* buf = rc == JTK_OK ? (uint8_t*)malloc((size_t)len + 1) : NULL;
-    if (rc == JTK_OK) rc = jtk_decode((const jtk_encoding*)(intptr_t)h, (const int32_t*)p, n, buf, len, &len);
+    if (rc == JTK_OK) rc = jtk_decode(ENC(h), (const int32_t*)p, n, buf, len, &len);
     (*env)->ReleaseIntArrayElements(env, ids, p, JNI_ABORT);
     if (rc != JTK_OK) { free(buf); throw_for(env, rc); return NULL; }
     jbyteArray out = (*env)->NewByteArray(env, (jsize)len);
     (*env)->SetByteArrayRegion(env, out, 0, (jsize)len, (const jbyte*)buf);
     free(buf);
     return out;
+}
+
+/* page-locked direct buffers: the device reads the documents by DMA from where the JVM put them */
+JNIEXPORT jobject JNICALL FN(nativeHostAlloc)(JNIEnv* env, jclass c, jlong bytes) {
+    (void)c;
+    void* p = NULL;
+    int rc = jtk_host_alloc((size_t)bytes, &p);
+    if (rc != JTK_OK) { throw_for(env, rc); return NULL; }
+    return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+JNIEXPORT void JNICALL FN(nativeHostFree)(JNIEnv* env, jclass c, jobject buffer) {
+    (void)c;
+    jtk_host_free((*env)->GetDirectBufferAddress(env, buffer));
 }

@@ -183,3 +183,29 @@ def test_shard_plan_matches_python_reference():
         assert b[0] == 0 and b[-1] == len(doc_off) - 1 and all(x <= y for x, y in zip(b, b[1:]))
         sizes = [int(doc_off[b[r + 1]] - doc_off[b[r]]) for r in range(world)]
         assert max(sizes) - min(sizes) <= 2 * 8192
+
+
+def _build_mirror_smoke(tmp_path):
+    exe = os.path.join(str(tmp_path), "mirror_smoke")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "mirror_smoke.cpp"),
+                           "-L" + os.path.join(ROOT, "jtokkit_amd"), "-ljtokkit_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "jtokkit_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_mirror_compiles_and_fails_loudly_without_a_device(tmp_path):
+    """jtokkit_amd/csrc/jtk_encoding.hpp (the C++ face of the boundary) builds against the C ABI; without a HIP device its
+    constructor throws the mapped exception -- there is no CPU path behind it."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: covered by the gpu tier")
+    exe = _build_mirror_smoke(tmp_path)
+    p = subprocess.run([exe, os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken")], capture_output=True, text=True)
+    assert p.returncode == 3 and "no HIP device" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_encodes_on_the_device(tmp_path):
+    exe = _build_mirror_smoke(tmp_path)
+    p = subprocess.run([exe, os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken")], capture_output=True, text=True)
+    assert p.returncode == 0 and "mirror ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
