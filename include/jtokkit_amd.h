@@ -87,9 +87,12 @@ int jtk_device_count(void);
  * EncodingFactory.java:139-164), builds the device rank tables and uploads them to `device`.
  * `special_literals[i]` / `special_ids[i]` are the special tokens (EncodingFactory.java:24-53).
  *
- * Tables accepted: all 256 single bytes present, ids < 131071, and bytePairMerge(T) == [rank(T)]
- * for every table entry T (true for the three shipped tables), so that the whole-piece shortcut of
- * GptBytePairEncoding.java:81-83 is a pure optimisation; otherwise JTK_ERR_UNSUPPORTED_TABLE. */
+ * Tables accepted: any rank map with all 256 single bytes present (the reference cannot encode arbitrary text without
+ * them either) and ids < 131071; otherwise JTK_ERR_UNSUPPORTED_TABLE.  The whole-piece lookup of
+ * GptBytePairEncoding.java:81-83 is honoured for pieces of any length: for tables in which merging a token's bytes
+ * reproduces the token (every table trained by byte-pair merging; the three shipped ones) it is a pure shortcut, for others
+ * the unreproducible entries get a lookup of their own and the exact intra-piece cuts are switched off.
+ * Special tokens: at most 8 literals of 1..32 bytes (any first byte), ids < 131071 + 2^20. */
 int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tiktoken, size_t tiktoken_len,
                         const char* const* special_literals, const int32_t* special_ids, int n_specials,
                         int device, jtk_encoding** out);

@@ -57,7 +57,7 @@ int jtk_fail_msg(int code, const std::string& msg) { return fail(code, msg); }  
 struct jtk_encoding {
     JtkHostTables host;
     int device = 0;
-    DevBuf uc1, uc2, brank, pairs, tok8, tok16, bprank, bpbits, bpcum, bpranks, pairin, dec_off, dec_blob;
+    DevBuf uc1, uc2, brank, pairs, tok8, tok16, bprank, bpbits, bpcum, bpranks, pairin, dec_off, dec_blob, longtok, longblob;
     uint32_t n_ids_table = 0;        // ids 0 .. n_ids_table-1 have an entry in the decode table (incl. special tokens)
     JtkDeviceTables dt;
     std::vector<uint32_t> tok_len;   // byte length per id (0 = absent), for the maxTokens back-off
@@ -171,7 +171,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     }
     if (device < 0 || device >= ndev) { delete enc; return fail(JTK_ERR_INVALID_ARGUMENT, "device index out of range"); }
     enc->device = device;
-    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); delete enc; };
+    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); enc->longtok.release(); enc->longblob.release(); delete enc; };
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(JTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     ENC_TRY(hipSetDevice(device));
     if (enc->uc1.ensure(sizeof(jtk_uc_stage1_init)) || enc->uc2.ensure(sizeof(jtk_uc_stage2_init)) ||
@@ -206,9 +206,18 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
         ENC_TRY(hipMemcpy(enc->dec_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
         enc->n_ids_table = n_ids;
     }
+    if (!enc->host.long_tok.empty()) {
+        if (enc->longtok.ensure(enc->host.long_tok.size() * sizeof(JtkLongTokSlot)) || enc->longblob.ensure(enc->host.long_blob.size())) { cleanup(); return JTK_ERR_OUT_OF_MEMORY; }
+        ENC_TRY(hipMemcpy(enc->longtok.p, enc->host.long_tok.data(), enc->host.long_tok.size() * sizeof(JtkLongTokSlot), hipMemcpyHostToDevice));
+        ENC_TRY(hipMemcpy(enc->longblob.p, enc->host.long_blob.data(), enc->host.long_blob.size(), hipMemcpyHostToDevice));
+    }
 #undef ENC_TRY
     JtkDeviceTables& dt = enc->dt;
     memset(&dt, 0, sizeof(dt));
+    dt.longtok.slots = (const JtkLongTokSlot*)enc->longtok.p;
+    dt.longtok.blob = (const uint8_t*)enc->longblob.p;
+    dt.longtok.n = (uint32_t)enc->host.long_tok.size();
+    dt.longtok.max_len = enc->host.long_max_len;
     dt.uc.stage1 = (const uint8_t*)enc->uc1.p;
     dt.uc.stage2 = (const uint32_t*)enc->uc2.p;
     dt.uc_stage1_len = JTK_UC_STAGE1_LEN;
@@ -241,7 +250,7 @@ void jtk_encoding_destroy(jtk_encoding* enc) {
     (void)hipSetDevice(enc->device);
     enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release();
     enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release();
-    enc->dec_off.release(); enc->dec_blob.release();
+    enc->dec_off.release(); enc->dec_blob.release(); enc->longtok.release(); enc->longblob.release();
     delete enc;
 }
 const char* jtk_encoding_name(const jtk_encoding* enc) { return enc ? enc->host.name.c_str() : ""; }
@@ -546,6 +555,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         jtk_launch_piece_resolve(w, enc->dt, cst);
         end();
         begin();
+        jtk_launch_long_shortcut(w, enc->dt, cst);                  // (only for rank tables with entries merging cannot reproduce)
         jtk_launch_bpe_merge(w, enc->dt, cst);
         end();
         begin();

@@ -203,6 +203,25 @@ JTK_HD uint32_t jtk_tok16_find(const JtkTok16Table& t, const uint32_t (&k)[4], u
     return JTK_RANK_NONE;
 }
 
+// ---- whole-piece table for table entries of more than 16 bytes that bytePairMerge does not reproduce ---------------
+// GptBytePairEncoding.java:81-83 applies the whole-piece lookup to pieces of any length.  For a rank table in which merging
+// a token's bytes yields exactly that token (every table trained by byte-pair merging; the three shipped ones) the lookup is
+// a pure shortcut and the device applies it to pieces of <= 16 bytes only.  Hand-made tables may hold longer entries that
+// merging cannot produce: those (and only those) are listed here and looked up by a small kernel before the merge.
+// Open addressing, linear probing, load <= 0.5; key = 64-bit FNV-1a of the bytes, verified against the bytes themselves.
+struct JtkLongTokSlot {
+    uint32_t h_lo, h_hi, id, len;       // len == 0: empty
+    uint32_t blob_off, pad0, pad1, pad2;
+};
+struct JtkLongTokTable {
+    const JtkLongTokSlot* slots;
+    const uint8_t* blob;
+    uint32_t n;                         // slots (0: the encoding needs no such lookups)
+    uint32_t max_len;
+};
+JTK_HD uint64_t jtk_fnv1a_step(uint64_t h, uint32_t b) { return (h ^ (uint64_t)b) * 0x100000001B3ull; }
+#define JTK_FNV_BASIS 0xCBF29CE484222325ull
+
 // ---- Unicode class lookup ----------------------------------------------------------------------------
 struct JtkUcTables {
     const uint8_t* stage1;    // [0x1100]  cp >> 8 -> block

@@ -21,6 +21,7 @@
 // add every piece's token count to tile_tot[tile] (piece_resolve stored the resolved pieces' count there).
 #define JTK_QE_POS_MASK ((1ull << 37) - 1ull)
 #define JTK_QE_LEN_SHIFT 37
+#define JTK_QE_DONE (1ull << 63)       // the piece is a table entry found by k_long_shortcut: its result is in place already
 #define JTK_NBINS 5
 #define JTK_Q_SHARDS 64
 #define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
@@ -50,6 +51,7 @@ struct JtkDeviceTables {
     const uint32_t* bp_rank;     // [65536]
     JtkBpLds bp;                 // the same, compressed (staged into LDS by bpe_merge)
     const uint32_t* pair_in_token;   // [2048] bit (b0 << 8 | b1): adjacent inside some table entry
+    JtkLongTokTable longtok;         // table entries of > 16 bytes that merging does not reproduce (n == 0 for the shipped tables)
     int kind;
     int n_specials;
     uint8_t special_len[JTK_MAX_SPECIALS];
@@ -176,6 +178,7 @@ void jtk_launch_mark_pieces(const JtkWork& w, const int64_t* begin, const int64_
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
+void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);     // only if t.longtok.n
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);

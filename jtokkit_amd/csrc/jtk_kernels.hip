@@ -744,10 +744,11 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
 
     for (uint32_t base = kq * THREADS; base < count; base += K * THREADS) {
         const uint32_t qi = base + (uint32_t)tid;
-        const bool have = qi < count;
+        bool have = qi < count;
         uint64_t meta = 0;
         uint4 by = make_uint4(0, 0, 0, 0);
         if (have) { meta = qm[qi]; if (BIN == 0) by = qd[qi]; }
+        if (BIN > 0 && (meta & JTK_QE_DONE)) have = false;          // a table entry of > 16 bytes: result and count are in place
         const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
         const int len = have ? (int)((meta >> JTK_QE_LEN_SHIFT) & 255u) + 1 : 0;
         M alive;
@@ -1029,7 +1030,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
             pos = (int64_t)(entry & JTK_QE_POS_MASK);
             len = (int)((entry >> JTK_QE_LEN_SHIFT) & 255u) + 1;
             tpart = 0;
-            st = ST_TEXT;
+            st = (entry & JTK_QE_DONE) ? ST_NEED : ST_TEXT;       // (found by k_long_shortcut: nothing to merge)
         } else if (st == ST_TEXT) {
             // park this 64-byte slab of the window in the (idle) rank slots until the expansion batch runs
             uint32_t* park = rk + 16 * tpart * THREADS;
@@ -1202,6 +1203,7 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
     const uint32_t cnt = (CAP == JTK_MID_CAP) ? *w.mid_count : *w.long_count;
     for (uint32_t i = wave_id; i < cnt; i += n_waves) {
         const JtkLongPiece lp = list[i];
+        if (lp.len <= 0) continue;                                 // found by k_long_shortcut
         const int len = (int)lp.len;
         for (int j = lane; j < len; j += WAVE) {
             const uint32_t b0 = w.text[lp.start + j];
@@ -1257,6 +1259,7 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
     constexpr int CH = JTK_GIANT_CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = blockDim.x, NWV = NT >> 6;
     const JtkLongPiece lp = w.giant_list[gi];
+    if (lp.len <= 0) return;                                      // found by k_long_shortcut (workgroup-uniform)
     const int len = (int)lp.len;
     uint32_t* gid = w.htok + lp.start;
     uint32_t* grk = w.docpre + lp.start;
@@ -1636,6 +1639,63 @@ __global__ void __launch_bounds__(256) k_doc_offsets(JtkWork w) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// long_shortcut: GptBytePairEncoding.java:81-83 for queued pieces of more than 16 bytes, for rank tables that hold
+// entries of that length which bytePairMerge does not reproduce (jtk_common.h, JtkLongTokTable; never launched for the
+// shipped tables).  One lane per queued piece: FNV-1a of its bytes, probe, byte-wise verification; a hit becomes the
+// piece's one-token result right here and the merge kernels skip it.
+// ---------------------------------------------------------------------------------------------------
+__device__ uint32_t long_lookup(const JtkWork& w, const JtkDeviceTables& t, int64_t pos, int64_t len) {
+    if (len > (int64_t)t.longtok.max_len || len <= 16) return JTK_RANK_NONE;
+    uint64_t h = JTK_FNV_BASIS;
+    for (int64_t j = 0; j < len; j++) h = jtk_fnv1a_step(h, w.text[pos + j]);
+    const uint32_t n = t.longtok.n;
+    for (uint32_t i = (uint32_t)(h % n), probes = 0; probes < n; i = (i + 1) % n, probes++) {
+        const JtkLongTokSlot sl = t.longtok.slots[i];
+        if (sl.len == 0) return JTK_RANK_NONE;
+        if (sl.h_lo == (uint32_t)h && sl.h_hi == (uint32_t)(h >> 32) && sl.len == (uint32_t)len) {
+            bool eq = true;
+            for (int64_t j = 0; j < len && eq; j++) eq = t.longtok.blob[sl.blob_off + j] == w.text[pos + j];
+            if (eq) return sl.id;
+        }
+    }
+    return JTK_RANK_NONE;
+}
+
+__global__ void __launch_bounds__(256) k_long_shortcut(JtkWork w, JtkDeviceTables t) {
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
+    for (int bin = 1; bin < JTK_NBINS; bin++) {
+        for (int shard = 0; shard < JTK_Q_SHARDS; shard++) {
+            const uint32_t count = w.q_count[bin * JTK_Q_SHARDS + shard];
+            uint64_t* qm = w.qm[bin] + (int64_t)shard * w.q_cap[bin];
+            uint4* qd = w.qd[bin] + (int64_t)shard * w.q_cap[bin];
+            for (uint32_t i = gtid; i < count; i += gn) {
+                const uint64_t meta = qm[i];
+                const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
+                const uint32_t id = long_lookup(w, t, pos, (int64_t)((meta >> JTK_QE_LEN_SHIFT) & 255u) + 1);
+                if (id != JTK_RANK_NONE) {
+                    qd[i] = make_uint4(id, 0u, 0u, 0u);               // one token (count - 1 = 0 in the top byte)
+                    qm[i] = meta | JTK_QE_DONE;
+                    atomicAdd(&w.tile_tot[pos / T], 1u);
+                }
+            }
+        }
+    }
+    for (int which = 0; which < 3; which++) {
+        JtkLongPiece* list = which == 0 ? w.mid_list : which == 1 ? w.long_list : w.giant_list;
+        const uint32_t count = which == 0 ? *w.mid_count : which == 1 ? *w.long_count : *w.n_giant;
+        for (uint32_t i = gtid; i < count; i += gn) {
+            const JtkLongPiece lp = list[i];
+            const uint32_t id = long_lookup(w, t, lp.start, lp.len);
+            if (id != JTK_RANK_NONE) {
+                w.htok[lp.start] = id | (1u << JTK_HT_CNT_SHIFT);    // header: one token
+                list[i].len = 0;
+                atomicAdd(&w.tile_tot[lp.start / T], 1u);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // chunk c of a large batch starts at the first document at or after byte c * chunk_bytes
@@ -1732,6 +1792,9 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
 }
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
+}
+void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
+    if (t.longtok.n) hipLaunchKernelGGL(k_long_shortcut, dim3(256), dim3(256), 0, s, w, t);
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_merge, dim3(JTK_Q_SHARDS * ML_WGS_PER_SHARD), dim3(ML_THREADS), 0, s, w, t);

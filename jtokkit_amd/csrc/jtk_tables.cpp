@@ -307,6 +307,7 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
     // token on its own yields exactly that token.
     JtkPairTable pt{t.pair_buckets.data(), t.pair_bits};
     std::vector<uint32_t> ids, rk;
+    std::vector<const std::pair<const std::string, uint32_t>*> unrep_long;
     for (auto& kv : t.bytes_to_id) {
         const std::string& T = kv.first;
         bool ok;
@@ -332,10 +333,31 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
             ok = (v.size() == 1 && v[0] == kv.second);
         }
         if (!ok) {
-            err = "rank table has an entry that bytePairMerge does not reproduce; the whole-piece shortcut "
-                  "would change results (unsupported on the device path)";
-            return JTK_ERR_UNSUPPORTED_TABLE;
+            t.n_unreproducible++;
+            if (T.size() > 16) unrep_long.push_back(&kv);
         }
+    }
+    if (t.n_unreproducible) {
+        // The intra-piece cuts of pretok_split assume that encoding the two sides of a cut separately equals merging the
+        // whole piece; with an entry that merging does not reproduce a side could hit the whole-piece lookup where the
+        // reference (looking up the whole regex piece only) merges.  No cuts for such tables.
+        t.pair_in_token.assign(2048, 0xFFFFFFFFu);
+    }
+    if (!unrep_long.empty()) {
+        uint32_t ns = 16;
+        while (ns < unrep_long.size() * 2 + 16) ns <<= 1;
+        t.long_tok.assign(ns, JtkLongTokSlot{0, 0, 0, 0, 0, 0, 0, 0});
+        for (auto* kv : unrep_long) {
+            const std::string& T = kv->first;
+            uint64_t h = JTK_FNV_BASIS;
+            for (unsigned char c : T) h = jtk_fnv1a_step(h, c);
+            uint32_t i = (uint32_t)(h % ns);
+            while (t.long_tok[i].len) i = (i + 1) % ns;
+            t.long_tok[i] = JtkLongTokSlot{(uint32_t)h, (uint32_t)(h >> 32), kv->second, (uint32_t)T.size(), (uint32_t)t.long_blob.size(), 0, 0, 0};
+            t.long_blob += T;
+            if (T.size() > t.long_max_len) t.long_max_len = (uint32_t)T.size();
+        }
+        t.long_blob.append(16, '\0');
     }
 
     t.specials.clear();

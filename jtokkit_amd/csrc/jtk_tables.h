@@ -34,6 +34,12 @@ struct JtkHostTables {
     uint32_t pair_bits = 0;
     int64_t n_pairs = 0;
     int64_t pair_displaced = 0, tok8_displaced = 0;   // entries living in their secondary bucket
+    // table entries that bytePairMerge of their own bytes does not reproduce (hand-made tables): the whole-piece lookup is
+    // then more than a shortcut.  <= 16 bytes: the tok8 / tok16 tables cover them; longer ones are listed in long_tok.
+    int64_t n_unreproducible = 0;
+    std::vector<JtkLongTokSlot> long_tok;
+    std::string long_blob;
+    uint32_t long_max_len = 0;
     int64_t n_tokens = 0;
     uint32_t max_id = 0;
 };

@@ -782,3 +782,44 @@ def test_custom_pattern_pieces_path(jt):
     with pytest.raises(jt.EncodingError):
         b.encode_pieces(t, np.array([0, 7, len(t)]), np.array([5]), np.array([9]))            # crosses a document boundary
     b.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_hand_made_rank_table_with_unreproducible_entries(jt, kind):
+    """The reference accepts ANY rank map (api/GptBytePairEncodingParams.java:36-46, EncodingFactory.java:117-119) and looks every
+    regex piece up whole before merging (GptBytePairEncoding.java:81-83).  A hand-made table may hold entries that merging
+    their bytes cannot produce -- short ones (<= 16 bytes), long ones (more than 16, up to hundreds), and ones whose pieces
+    would otherwise be cut inside.  Special tokens with arbitrary first bytes ride along.  GPU == oracle built from the same
+    table."""
+    import base64
+    from jtokkit_amd import corpus
+    ranks = _train_tiny_bpe(corpus.english(40, seed=5)[0].tobytes(), 400)
+    extra = [b"zzzzqqqq", b"qzqzqz", b"abcdefghijklmnopqrstuvwxyz", b" internationalisation", b"x" * 40, b"0123456789" * 9,
+             " мультибайтовыйтокен".encode(), b"ab" * 150, b"\n\n\n\n\n\n\n\n\n\n\n\n\n\n\n\n\n\n\n\n"]
+    for e in extra:
+        assert e not in ranks
+        ranks[e] = len(ranks) + 7          # also leaves holes in the rank range
+    specials = {"[[stop]]": 100000, "~end~": 100001, "<|x|>": 100002}
+    enc = jt.new_custom_encoding("handmade_%d" % kind, kind, ranks, specials)
+    data = b"\n".join(base64.b64encode(k) + b" " + str(v).encode() for k, v in sorted(ranks.items(), key=lambda kv: kv[1])) + b"\n"
+    o = oracle_lib.OracleEncoding("handmade_%d" % kind, kind, data, specials)
+    rng = random.Random(kind)
+    texts = []
+    for e in extra:
+        s = e.decode("utf-8")
+        texts += [s, s + s, "a " + s + " b", s + "s", "(" + s + ")", s[:-1], s[1:], " " + s, s + "\n" + s]
+    texts += [rc.random_text(rng, rng.randint(0, 120)) for _ in range(300)]
+    texts += [" ".join(rng.choice([e.decode("utf-8") for e in extra] + ["the", "of", "x", "zzzz", "qqqq"]) for _ in range(rng.randint(1, 40))) for _ in range(200)]
+    _assert_batch_equals_oracle(enc, o, texts)
+    # the whole entries really come out as ONE token where the pattern keeps them in one piece
+    assert enc.encode_ordinary("abcdefghijklmnopqrstuvwxyz") == [ranks[b"abcdefghijklmnopqrstuvwxyz"]]
+    assert enc.encode_ordinary("zzzzqqqq") == [ranks[b"zzzzqqqq"]]
+    assert enc.encode_ordinary("ab" * 150) == [ranks[b"ab" * 150]]
+    # special tokens that do not start with "<|"
+    for t in ("say [[stop]] now", "the ~end~", "<|x|>"):
+        with pytest.raises(jt.UnsupportedOperationError):
+            enc.encode(t)
+        assert enc.encode_ordinary(t) == o.encode_ordinary(t)
+    assert enc.encode("[stop]] ~end <|x") == o.encode("[stop]] ~end <|x")
+    assert enc.decode([100000, 100001]) == "[[stop]]~end~"
+    enc.close()
