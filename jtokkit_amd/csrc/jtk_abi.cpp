@@ -376,7 +376,7 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t nt = (size_t)w.n_tiles;
-    const size_t qcnt_bytes = JTK_NBINS * JTK_Q_SHARDS * 4;
+    const size_t qcnt_bytes = (JTK_NBINS + 1) * JTK_Q_SHARDS * 4;
     const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
@@ -387,7 +387,7 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
         (rc = cs.docpre.ensure(nt * JTK_TILE * 4)) ||
         (rc = cs.tile_np.ensure(align_up(nt * 4, 16) * 2)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
         (rc = cs.q_meta.ensure(nt * 4 * 16)) ||
-        (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * (size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 24)) ||
+        (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * ((size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 24 + (size_t)JTK_TINY_CAP * 8))) ||
         (rc = cs.mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
@@ -419,6 +419,8 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
             w.qm[k] = (uint64_t*)qp;
             qp += tps * caps[k] * JTK_Q_SHARDS * 8;
         }
+        w.qt = (uint64_t*)qp;
+        w.qt_cap = (int64_t)(tps * JTK_TINY_CAP);
     }
     w.giant_cnt = (uint32_t*)cs.giant_cnt.p;
     w.mid_list = (JtkLongPiece*)cs.mid_list.p;

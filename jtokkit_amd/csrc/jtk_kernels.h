@@ -23,6 +23,13 @@
 #define JTK_QE_LEN_SHIFT 37
 #define JTK_QE_DONE (1ull << 63)       // the piece is a table entry found by k_long_shortcut: its result is in place already
 #define JTK_NBINS 5
+// Pieces of 2 or 3 bytes that are not table entries need no pair-table lookup at all (at most one merge of a 2-byte token;
+// the pair that would follow is the whole piece, which is not an entry).  They get a queue of their own ("bin" JTK_BIN_TINY
+// of a piece-list entry) with 8-byte entries that carry the bytes: pos (37 bits) | (len - 2) << 37 | b0 << 40 | b1 << 48 |
+// b2 << 56; the merge kernel replaces an entry by its result: up to three token ids, 17 bits each from bit 0 (the first 64
+// bits of a merge result word), | (count - 1) << 62.
+#define JTK_BIN_TINY 5
+#define JTK_TINY_CAP (JTK_TILE / 2)
 #define JTK_Q_SHARDS 64
 #define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
 #define JTK_BIN_CAP1 (JTK_TILE / 16)   //           17..32 bytes
@@ -115,7 +122,9 @@ struct JtkWork {
     uint64_t* qm[JTK_NBINS];        // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k: position and length
     uint4* qd[JTK_NBINS];           // [JTK_Q_SHARDS][q_cap[k]] ... : bytes in (bin 0), merge result out
     int64_t q_cap[JTK_NBINS];       // entries per shard
-    uint32_t* q_count;              // [JTK_NBINS][JTK_Q_SHARDS]
+    uint64_t* qt;                   // [JTK_Q_SHARDS][qt_cap] the queue of JTK_BIN_TINY: bytes in, result out
+    int64_t qt_cap;
+    uint32_t* q_count;              // [JTK_NBINS + 1][JTK_Q_SHARDS]
     uint32_t* q_meta;               // [n_tiles][16]: [k] where in its shard the tile's entries of bin k start, [8 + k] how many
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces

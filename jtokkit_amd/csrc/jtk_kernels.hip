@@ -375,7 +375,7 @@ constexpr int TW = T / 64;                                          // mask word
 static_assert(TW <= 64, "tile scans assume at most 64 mask words");
 
 constexpr int Q_OFF0 = 0, Q_OFF1 = JTK_BIN_CAP0, Q_OFF2 = Q_OFF1 + JTK_BIN_CAP1, Q_OFF3 = Q_OFF2 + JTK_BIN_CAP2,
-              Q_OFF4 = Q_OFF3 + JTK_BIN_CAP3, Q_TOTAL = Q_OFF4 + JTK_BIN_CAP4;
+              Q_OFF4 = Q_OFF3 + JTK_BIN_CAP3, Q_OFF5 = Q_OFF4 + JTK_BIN_CAP4, Q_TOTAL = Q_OFF5 + JTK_TINY_CAP;
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ uint64_t s_pm[TW];
     __shared__ uint64_t s_gap[TW];
     __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
-    __shared__ uint32_t s_qn[JTK_NBINS], s_qb[JTK_NBINS], s_nhard;
+    __shared__ uint32_t s_qn[JTK_NBINS + 1], s_qb[JTK_NBINS + 1], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         s_pm[tid] = m;
         s_gap[tid] = (w.gapmask && wd < w.n_words) ? w.gapmask[wd] : 0ull;
     }
-    if (tid < JTK_NBINS) s_qn[tid] = 0;
+    if (tid < JTK_NBINS + 1) s_qn[tid] = 0;
     if (tid == 0) s_nhard = 0;
     if (tid == 64) {
         int64_t pos = -1;                                             // scan ahead for the next piece start
@@ -508,7 +508,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             w.htok[B + s] = 0u;
             atomicAdd(&s_nhard, 1u);
         } else if (len <= 16) {
-            if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT); else bin = 0;
+            if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT);
+            else bin = (len <= 3) ? JTK_BIN_TINY : 0;                // (a 1-byte piece is always a table entry)
         } else if (len <= 32) bin = 1;
         else if (len <= 64) bin = 2;
         else if (len <= 128) bin = 3;
@@ -533,21 +534,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             atomicAdd(&s_nhard, 1u);
         }
         if (bin >= 0) {
-            const int qoff = bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : Q_OFF4;
+            const int qoff = bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : bin == 4 ? Q_OFF4 : Q_OFF5;
             const uint32_t i = atomicAdd(&s_qn[bin], 1u);
             s_q[qoff + i] = (uint32_t)s | ((uint32_t)(len - 1) << 11) | (i << 19);
             entry = JTK_PL_HARD | ((uint32_t)bin << JTK_PL_BIN_SHIFT) | (i << JTK_PL_QI_SHIFT) | (uint32_t)s;
         }
         plist[k] = entry;
     };
-    for (int k0 = 0; k0 < np; k0 += 2 * 256) {
+    // Pieces are taken in chunks of 64 (chunk c: pieces 64 c .. 64 c + 63); wave wv takes chunks wv, wv + 4, wv + 8, ... two at
+    // a time while there are two (so that two probes per lane are in flight), one otherwise: a tile of 530 pieces costs nine
+    // chunk passes, not the sixteen of two full rounds of 512.
+    for (int c0 = wv; c0 * 64 < np; c0 += 8) {
+        const bool two = (c0 + 4) * 64 < np;                               // wave-uniform
+        const int ka = c0 * 64 + lane, kb = (c0 + 4) * 64 + lane;
         Probe p0, p1;
-        issue(k0 + tid, p0);
-        issue(k0 + 256 + tid, p1);
-        uint32_t id0, id1;
-        bool more0, more1;
+        issue(ka, p0);
+        if (two) issue(kb, p1); else { p1.s = -1; p1.len = 0; }
+        uint32_t id0, id1 = JTK_RANK_NONE;
+        bool more0, more1 = false;
         check(p0, id0, more0);
-        check(p1, id1, more1);
+        if (two) check(p1, id1, more1);
         more0 = more0 && p0.s >= 0 && p0.len <= 16;
         more1 = more1 && p1.s >= 0 && p1.len <= 16;
         if (__ballot(more0 || more1)) {
@@ -557,8 +563,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             if (more0) check(p0, id0, dummy);
             if (more1) check(p1, id1, dummy);
         }
-        resolve(k0 + tid, p0, id0);
-        resolve(k0 + 256 + tid, p1, id1);
+        resolve(ka, p0, id0);
+        if (two) resolve(kb, p1, id1);
     }
     __syncthreads();
     // The tile's slices of its queue shards are claimed with one returning atomic per bin (a device-wide atomic:
@@ -566,12 +572,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     // piece's bytes (so that the merge kernel reads 16 dense bytes per piece instead of a 64-byte slab of the text).
     // A tile with few merge pieces (ordinary text) leaves that to wave 0; the other waves are done and leave, so
     // their slots go to the next tile's workgroup while the atomic is in flight.
-    const uint32_t n_queued = s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4];
+    const uint32_t n_queued = s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4] + s_qn[JTK_BIN_TINY];
     const bool all_waves = n_queued > 64u;                           // workgroup-uniform
     if (!all_waves && wv != 0) return;
     if (wv == 0) {
         uint32_t nq = 0, qb = 0;
-        if (lane < JTK_NBINS) {
+        if (lane < JTK_NBINS + 1) {
             nq = s_qn[lane];
             qb = nq ? atomicAdd(&w.q_count[lane * JTK_Q_SHARDS + tile % JTK_Q_SHARDS], nq) : 0u;
             w.q_meta[tile * 16 + lane] = qb;
@@ -599,6 +605,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             w.qd[0][qbase + i] = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
                                             __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
             w.qm[0][qbase + i] = (uint64_t)(B + off) | ((uint64_t)((e >> 11) & 255u) << JTK_QE_LEN_SHIFT);
+        }
+    }
+    {   // tiny pieces: position, length and the 2..3 bytes in one word
+        const uint32_t nq5 = s_qn[JTK_BIN_TINY];
+        uint64_t* dst = w.qt + (tile % JTK_Q_SHARDS) * w.qt_cap + s_qb[JTK_BIN_TINY];
+        const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
+        for (uint32_t i = (uint32_t)me; i < nq5; i += (uint32_t)nthr) {
+            const uint32_t e = s_q[Q_OFF5 + i];
+            const uint32_t off = e & 2047u, len = ((e >> 11) & 255u) + 1u;
+            const int a = (int)(off >> 2);
+            uint32_t by = __builtin_amdgcn_alignbyte(tw[a + 1], tw[a], off & 3u) & 0xFFFFFFu;
+            if (len == 2u) by &= 0xFFFFu;
+            dst[i] = (uint64_t)(B + off) | ((uint64_t)(len - 2u) << 37) | ((uint64_t)by << 40);
         }
     }
 #pragma unroll
@@ -728,6 +747,48 @@ __device__ __forceinline__ uint32_t lean_piece16(const LeanLds& L, uint32_t* id,
     }
     const uint32_t alive0 = (1u << len) - 1u;
     return lean_steps<NS, STRIDE, true, uint32_t>(id, rk, alive0, reinterpret_cast<const uint8_t*>(t.pairs.buckets), t.pairs.bits);
+}
+
+// the tiny queue: pieces of 2 or 3 bytes that are not table entries.  bytePairMerge (GptBytePairEncoding.java:200-275) of
+// such a piece makes no lookup that can hit beyond the 2-byte-token ranks of its byte pairs: merge the pair of lower rank,
+// the left one on a tie (:236), if either is a token; the pair that would follow is the whole piece, which is no entry.
+template <int THREADS>
+__device__ __forceinline__ void tiny_bin(const JtkWork& w, const LeanLds& L, uint32_t count) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int shard = blockIdx.x % JTK_Q_SHARDS;
+    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
+    uint64_t* const q = w.qt + (int64_t)shard * w.qt_cap;
+    for (uint32_t base = kq * THREADS; base < count; base += K * THREADS) {
+        const uint32_t qi = base + (uint32_t)tid;
+        const bool have = qi < count;
+        const uint64_t e = have ? q[qi] : 0ull;
+        const int64_t pos = (int64_t)(e & JTK_QE_POS_MASK);
+        const bool three = ((e >> 37) & 1ull) != 0;
+        const uint32_t b0 = (uint32_t)(e >> 40) & 255u, b1 = (uint32_t)(e >> 48) & 255u, b2 = (uint32_t)(e >> 56) & 255u;
+        const uint32_t r01 = three ? jtk_bp_lookup(L.bp, (b0 << 8) | b1) : JTK_RANK_NONE;
+        const uint32_t r12 = three ? jtk_bp_lookup(L.bp, (b1 << 8) | b2) : JTK_RANK_NONE;
+        const uint32_t i0 = L.brank[b0], i1 = L.brank[b1], i2 = L.brank[b2];
+        uint32_t t0 = i0, t1 = i1, t2 = i2, c = three ? 3u : 2u;
+        if (r01 != JTK_RANK_NONE && r01 <= r12) { t0 = r01; t1 = i2; c = 2u; }
+        else if (r12 != JTK_RANK_NONE) { t1 = r12; c = 2u; }
+        if (c == 2u) t2 = 0u;
+        if (have) q[qi] = (uint64_t)t0 | ((uint64_t)t1 << 17) | ((uint64_t)t2 << 34) | ((uint64_t)(c - 1u) << 62);
+        // token counts per tile (as in lean_bin)
+        const int64_t tile = have ? pos / T : -1;
+        const uint32_t cc = have ? c : 0u;
+        const uint32_t inc = wave_incl_scan(cc);
+        const uint32_t tlo = (uint32_t)tile, thi = (uint32_t)((uint64_t)tile >> 32);
+        const uint32_t plo = (uint32_t)__shfl_up((int)tlo, 1), phi = (uint32_t)__shfl_up((int)thi, 1);
+        const bool head = lane == 0 || plo != tlo || phi != thi;
+        const uint64_t heads = __ballot(head);
+        const uint64_t later = heads & ~((2ull << lane) - 1ull);
+        const int last = later ? jtk_ctz64(later) - 1 : 63;
+        const uint32_t run_end = (uint32_t)__shfl((int)inc, last);
+        if (head && have) {
+            const uint32_t sum = run_end - (inc - cc);
+            if (sum) atomicAdd(&w.tile_tot[tile], sum);
+        }
+    }
 }
 
 template <int SLOTS, int THREADS, int BIN>
@@ -1369,6 +1430,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     __shared__ uint32_t s_brank[256];
     __shared__ uint32_t s_next[JTK_NBINS];
     __shared__ uint32_t s_count[JTK_NBINS + 3];
+    __shared__ uint32_t s_ntiny;
     const int tid = threadIdx.x;
     const int shard = blockIdx.x % JTK_Q_SHARDS;
     const uint32_t kq = blockIdx.x / JTK_Q_SHARDS;
@@ -1376,6 +1438,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
         s_next[tid] = 0;
         s_count[tid] = w.q_count[tid * JTK_Q_SHARDS + shard];
     }
+    if (tid == 16) s_ntiny = w.q_count[JTK_BIN_TINY * JTK_Q_SHARDS + shard];
     if (tid == JTK_NBINS) s_count[JTK_NBINS] = *w.mid_count;
     if (tid == JTK_NBINS + 1) s_count[JTK_NBINS + 1] = *w.long_count;
     if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = *w.n_giant;
@@ -1384,13 +1447,16 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     const uint32_t n0 = s_count[0], n1 = s_count[1], n2 = s_count[2];
     const bool w0 = kq * (uint32_t)ML_THREADS < n0, w1 = kq * (uint32_t)(ML_THREADS / 2) < n1, w2 = kq * (uint32_t)(ML_THREADS / 4) < n2;
     const bool rest = (s_count[3] | s_count[4] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
-    if (!(w0 || w1 || w2 || rest)) return;
+    const uint32_t nt5 = s_ntiny;
+    const bool w5 = kq * (uint32_t)ML_THREADS < nt5;
+    if (!(w0 || w1 || w2 || w5 || rest)) return;
     s_bpbits[tid] = t.bp.bits[tid];
     s_bpcum[tid] = t.bp.cum[tid];
     for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
     if (tid < 256) s_brank[tid] = t.byte_rank[tid];
     __syncthreads();
     const LeanLds LL{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
+    if (w5) tiny_bin<ML_THREADS>(w, LL, nt5);                    // (no parts in LDS: no barrier needed before the next phase)
     if (w0) lean_bin<16, ML_THREADS, 0>(w, t, LL, n0);
     if (w1) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 1>(w, t, LL, n1); }
     if (w2) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 2>(w, t, LL, n2); }
@@ -1505,14 +1571,28 @@ template <int I> __device__ __forceinline__ uint32_t res_tok(const uint4& r) {
     return (sh + 17 <= 32 ? (w0 >> sh) : __builtin_amdgcn_alignbit(w1, w0, sh)) & JTK_HT_ID_MASK;
 }
 
-constexpr int PACK_STAGE = 1024;               // tokens of a tile assembled in LDS (ordinary text: a few hundred)
+#ifndef JTK_PACK_STAGE
+#define JTK_PACK_STAGE 768
+#endif
+#ifndef JTK_PACK_Q0
+#define JTK_PACK_Q0 64
+#endif
+#ifndef JTK_PACK_QH
+#define JTK_PACK_QH 16
+#endif
+#ifndef JTK_PACK_QT
+#define JTK_PACK_QT 128
+#endif
+constexpr int PACK_STAGE = JTK_PACK_STAGE;     // tokens of a tile assembled in LDS (ordinary text: a few hundred)
+constexpr int PQ0 = JTK_PACK_Q0, PQH = JTK_PACK_QH, PQT = JTK_PACK_QT;   // staged merge results: bin 0, bins 1..4 each, tiny pieces
 
 __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     // ONE WAVE PER TILE, no workgroup barriers.  A wave keeps a whole tile in flight: 8 list entries per lane, the head
     // of the tile's merge results (they are dense: the tile's slice of each bin's queue) and the document mask are all
     // requested before the first wait.  The tile's tokens are assembled in LDS (the few multi-token pieces make sparse
     // writes, cheap there and expensive in memory) and leave in full 256-byte stores.
-    __shared__ uint4 s_qe[128];
+    __shared__ uint4 s_qe[PQ0 + 4 * PQH];
+    __shared__ uint2 s_qt[PQT];                 // staged results of the tile's tiny pieces
     __shared__ uint64_t s_dm[TW];
     __shared__ uint32_t s_out[PACK_STAGE];
     const int lane = threadIdx.x;
@@ -1536,15 +1616,23 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     const int64_t shard = tile % JTK_Q_SHARDS;
     const uint32_t qb0 = (uint32_t)__shfl((int)meta, 0), nq0 = (uint32_t)__shfl((int)meta, 8);
     const uint4* const res0 = w.qd[0] + shard * w.q_cap[0] + qb0;
-    if ((uint32_t)lane < nq0) s_qe[lane] = res0[lane];
+    if ((uint32_t)lane < nq0 && lane < PQ0) s_qe[lane] = res0[lane];
     const uint32_t nq_hi = (uint32_t)__shfl((int)meta, 9) | (uint32_t)__shfl((int)meta, 10) | (uint32_t)__shfl((int)meta, 11) | (uint32_t)__shfl((int)meta, 12);
     if (nq_hi) {                                                          // wave-uniform; rare in ordinary text
         const int bq = 1 + (lane >> 4);
         const uint32_t qb = (uint32_t)__shfl((int)meta, bq), nq = (uint32_t)__shfl((int)meta, 8 + bq);
-        if ((uint32_t)(lane & 15) < nq) s_qe[64 + lane] = (w.qd[bq] + shard * w.q_cap[bq] + qb)[lane & 15];
+        if ((uint32_t)(lane & 15) < nq && (lane & 15) < PQH) s_qe[PQ0 + (bq - 1) * PQH + (lane & 15)] = (w.qd[bq] + shard * w.q_cap[bq] + qb)[lane & 15];
+    }
+    const uint32_t qb5 = (uint32_t)__shfl((int)meta, JTK_BIN_TINY), nq5 = (uint32_t)__shfl((int)meta, 8 + JTK_BIN_TINY);
+    const uint2* const res5 = reinterpret_cast<const uint2*>(w.qt + shard * w.qt_cap + qb5);
+    if (nq5) {                                                            // wave-uniform
+        if ((uint32_t)lane < nq5 && lane < PQT) s_qt[lane] = res5[lane];
+        if (PQT > 64 && (uint32_t)lane + 64u < nq5) s_qt[(64 + lane) % PQT] = res5[64 + lane];
     }
     wave_lds_fence();
     uint32_t run = 0;
+    // a tiny piece's 8-byte result as a merge result word: the ids are where res_tok<0..2> looks, the count moves up
+    auto tiny_word = [](uint2 r) { return make_uint4(r.x, r.y & 0x3FFFFFFFu, 0u, (r.y >> 30) << 24); };
     // one step: 64 consecutive pieces of the list, entry ej in lane order; out = s_out or dst
 #define STORE(x) do { if (store) { x; } } while (0)
     auto step = [&](uint32_t* out, uint32_t ej, int k) {
@@ -1552,9 +1640,11 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
         const bool hard = (ej & JTK_PL_HARD) != 0;
         const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
         const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
-        const bool staged = queued && (bin == 0 ? qi < 64u : qi < 16u);
-        const uint32_t sidx = staged ? (bin == 0 ? qi : 48u + bin * 16u + qi) : 0u;
+        const bool tinyp = bin == JTK_BIN_TINY;
+        const bool staged = queued && (bin == 0 ? qi < (uint32_t)PQ0 : tinyp ? qi < (uint32_t)PQT : qi < (uint32_t)PQH);
+        const uint32_t sidx = staged && !tinyp ? (bin == 0 ? qi : (uint32_t)PQ0 + (bin - 1u) * (uint32_t)PQH + qi) : 0u;
         uint4 qe = s_qe[sidx];
+        if (__ballot(queued && tinyp)) { if (staged && tinyp) qe = tiny_word(s_qt[qi]); }
         uint32_t c = valid ? (hard ? (qe.w >> 24) + 1u : 1u) : 0u;
         const uint32_t off = hard ? (ej & 2047u) : ((ej >> JTK_PL_OFF_SHIFT) & 2047u);
         const bool isdoc = valid && ((s_dm[off >> 6] >> (off & 63)) & 1ull);
@@ -1585,7 +1675,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             // by the wave / workgroup phases (count and tokens in htok)
             const uint32_t qb = (uint32_t)__shfl((int)meta, (int)(bin < JTK_NBINS ? bin : 0u));   // (all lanes take part)
             if (valid && queued && !staged) {
-                qe = (w.qd[bin] + shard * w.q_cap[bin] + qb)[qi];
+                qe = tinyp ? tiny_word(res5[qi]) : (w.qd[bin] + shard * w.q_cap[bin] + qb)[qi];
                 c = (qe.w >> 24) + 1u;
             } else if (valid && hard && !queued) c = hard_count(w, B + off);        // count in the htok header
             const uint32_t inc = wave_incl_scan(c);
