@@ -387,7 +387,7 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
         (rc = cs.docpre.ensure(nt * JTK_TILE * 4)) ||
         (rc = cs.tile_np.ensure(align_up(nt * 4, 16) * 2)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
         (rc = cs.q_meta.ensure(nt * 4 * 16)) ||
-        (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * ((size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4) * 24 + (size_t)JTK_TINY_CAP * 8))) ||
+        (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * ((size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4 + JTK_BIN_CAP5 + JTK_BIN_CAP6) * 24 + (size_t)JTK_TINY_CAP * 8))) ||
         (rc = cs.mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
@@ -407,7 +407,7 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.tile_tot = (uint32_t*)((uint8_t*)cs.tile_np.p + align_up(nt * 4, 16));
     w.tile_off = (int64_t*)cs.tile_off.p;
     {
-        const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4};
+        const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4, JTK_BIN_CAP5, JTK_BIN_CAP6};
         uint8_t* qp = (uint8_t*)cs.queues.p;                      // all the 16-byte arrays first, then the 8-byte ones
         w.q_meta = (uint32_t*)cs.q_meta.p;
         for (int k = 0; k < JTK_NBINS; k++) {

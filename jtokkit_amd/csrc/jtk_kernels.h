@@ -14,28 +14,40 @@
 // Queues are dense and sharded: tile t appends its entries to shard t % JTK_Q_SHARDS with one returning
 // atomic per tile and bin.  A queue entry is two words in two parallel arrays:
 //   qm  (8 bytes)   pos (37 bits) | (len - 1) << 37
-//   qd  (16 bytes)  bin 0: IN the piece's bytes (<= 16, what piece_resolve hashed), OUT the merge result;
-//                   bins 1..4: OUT the merge result (their bytes are read from the text)
+//   qd  (16 bytes)  bins 0..2: IN the piece's bytes (<= 16, what piece_resolve hashed), OUT the merge result;
+//                   bins 3..6: OUT the merge result (their bytes are read from the text)
 // Merge result: (token count - 1) in the top byte | up to seven token ids, 17 bits each from bit 0; a piece that
 // became more than seven tokens leaves its tokens in htok (packed from its first byte position).  The merge kernels
 // add every piece's token count to tile_tot[tile] (piece_resolve stored the resolved pieces' count there).
 #define JTK_QE_POS_MASK ((1ull << 37) - 1ull)
 #define JTK_QE_LEN_SHIFT 37
 #define JTK_QE_DONE (1ull << 63)       // the piece is a table entry found by k_long_shortcut: its result is in place already
-#define JTK_NBINS 5
+#define JTK_NBINS 7
 // Pieces of 2 or 3 bytes that are not table entries need no pair-table lookup at all (at most one merge of a 2-byte token;
 // the pair that would follow is the whole piece, which is not an entry).  They get a queue of their own ("bin" JTK_BIN_TINY
 // of a piece-list entry) with 8-byte entries that carry the bytes: pos (37 bits) | (len - 2) << 37 | b0 << 40 | b1 << 48 |
 // b2 << 56; the merge kernel replaces an entry by its result: up to three token ids, 17 bits each from bit 0 (the first 64
 // bits of a merge result word), | (count - 1) << 62.
-#define JTK_BIN_TINY 5
+#define JTK_BIN_TINY 7
 #define JTK_TINY_CAP (JTK_TILE / 2)
 #define JTK_Q_SHARDS 64
-#define JTK_BIN_CAP0 (JTK_TILE / 2)    // per tile: pieces of 2..16 bytes
-#define JTK_BIN_CAP1 (JTK_TILE / 16)   //           17..32 bytes
-#define JTK_BIN_CAP2 (JTK_TILE / 32)   //           33..64 bytes
-#define JTK_BIN_CAP3 (JTK_TILE / 64)   //           65..128 bytes
-#define JTK_BIN_CAP4 (JTK_TILE / 128)  //           129..256 bytes
+// Bins by length.  A wave of the merge kernel steps until its longest piece is done, so pieces of like length are queued
+// together: three classes up to 16 bytes (whose entries carry the piece's bytes), then powers of two.
+#define JTK_BIN_CAP0 (JTK_TILE / 4)    // per tile: pieces of 4..8 bytes (2..3-byte pieces: JTK_BIN_TINY)
+#define JTK_BIN_CAP1 (JTK_TILE / 8)    //           9..12 bytes
+#define JTK_BIN_CAP2 160               //           13..16 bytes (2048 / 13 = 157)
+#define JTK_BIN_CAP3 (JTK_TILE / 16)   //           17..32 bytes
+#define JTK_BIN_CAP4 (JTK_TILE / 32)   //           33..64 bytes
+#define JTK_BIN_CAP5 (JTK_TILE / 64)   //           65..128 bytes
+#define JTK_BIN_CAP6 (JTK_TILE / 128)  //           129..256 bytes
+// the head of a tile's slice of each bin's queue that pack stages in LDS: 32 + 16 + 16 results of the three classes of <= 16
+// bytes (staging slots 0..63), 8 of each longer bin (64..95); tiny pieces have a staging area of their own (JTK_PACK_TINY)
+#define JTK_PACK_TINY 128
+#define JTK_PACK_SLOTS 96
+#define JTK_PACK_CAP(bin) ((bin) == 0 ? 32 : (bin) <= 2 ? 16 : 8)
+#define JTK_PACK_OFF(bin) ((bin) == 0 ? 0 : (bin) == 1 ? 32 : (bin) == 2 ? 48 : 64 + ((bin) - 3) * 8)
+#define JTK_NBINS_BYTES 3              // bins 0..2: the queue entry carries the piece's bytes
+#define JTK_NBINS_LEAN 5               // bins 0..4: lean phases of the merge kernel; 5..6: state-machine phases
 #define JTK_BIN_MAXLEN 256            // longer pieces go to the wave-per-piece kernels
 #define JTK_M_WGS_PER_SHARD 4
 #define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
@@ -70,6 +82,8 @@ struct JtkDeviceTables {
 // the tile's slice of the bin's queue << 11) or JTK_PL_NOQUEUE (wave / workgroup kernels: tokens and count in htok).
 #define JTK_PL_HARD 0x80000000u
 #define JTK_PL_NOQUEUE 0x40000000u
+#define JTK_PL_STAGED 0x20000000u        // queued piece whose result is in the head of the tile's queue slice that pack stages in LDS:
+                                         // the index field then holds its staging slot (pack_stage_slot), not the index in the bin
 #define JTK_PL_OFF_SHIFT 17
 #define JTK_PL_QI_SHIFT 11
 #define JTK_PL_BIN_SHIFT 21

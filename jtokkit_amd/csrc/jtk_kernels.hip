@@ -374,8 +374,15 @@ constexpr int T = JTK_TILE;
 constexpr int TW = T / 64;                                          // mask words per tile
 static_assert(TW <= 64, "tile scans assume at most 64 mask words");
 
-constexpr int Q_OFF0 = 0, Q_OFF1 = JTK_BIN_CAP0, Q_OFF2 = Q_OFF1 + JTK_BIN_CAP1, Q_OFF3 = Q_OFF2 + JTK_BIN_CAP2,
-              Q_OFF4 = Q_OFF3 + JTK_BIN_CAP3, Q_OFF5 = Q_OFF4 + JTK_BIN_CAP4, Q_TOTAL = Q_OFF5 + JTK_TINY_CAP;
+// this tile's queued pieces by bin, in LDS until its slices of the queues are claimed
+__host__ __device__ __forceinline__ constexpr int q_off(int bin) {
+    return bin == 0 ? 0 : bin == 1 ? JTK_BIN_CAP0 : bin == 2 ? JTK_BIN_CAP0 + JTK_BIN_CAP1 : bin == 3 ? JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2
+         : bin == 4 ? JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3
+         : bin == 5 ? JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4
+         : bin == 6 ? JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4 + JTK_BIN_CAP5
+         : JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4 + JTK_BIN_CAP5 + JTK_BIN_CAP6;   // tiny
+}
+constexpr int Q_TOTAL = q_off(JTK_BIN_TINY) + JTK_TINY_CAP;
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
@@ -509,11 +516,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             atomicAdd(&s_nhard, 1u);
         } else if (len <= 16) {
             if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT);
-            else bin = (len <= 3) ? JTK_BIN_TINY : 0;                // (a 1-byte piece is always a table entry)
-        } else if (len <= 32) bin = 1;
-        else if (len <= 64) bin = 2;
-        else if (len <= 128) bin = 3;
-        else if (len <= JTK_BIN_MAXLEN) bin = 4;
+            else bin = (len <= 3) ? JTK_BIN_TINY : (len <= 8) ? 0 : (len <= 12) ? 1 : 2;   // (a 1-byte piece is always a table entry)
+        } else if (len <= 32) bin = 3;
+        else if (len <= 64) bin = 4;
+        else if (len <= 128) bin = 5;
+        else if (len <= JTK_BIN_MAXLEN) bin = 6;
         else {
             const int64_t len64 = piece_len(k, s);
             if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
@@ -534,10 +541,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             atomicAdd(&s_nhard, 1u);
         }
         if (bin >= 0) {
-            const int qoff = bin == 0 ? Q_OFF0 : bin == 1 ? Q_OFF1 : bin == 2 ? Q_OFF2 : bin == 3 ? Q_OFF3 : bin == 4 ? Q_OFF4 : Q_OFF5;
+            const int qoff = q_off(bin);
             const uint32_t i = atomicAdd(&s_qn[bin], 1u);
             s_q[qoff + i] = (uint32_t)s | ((uint32_t)(len - 1) << 11) | (i << 19);
-            entry = JTK_PL_HARD | ((uint32_t)bin << JTK_PL_BIN_SHIFT) | (i << JTK_PL_QI_SHIFT) | (uint32_t)s;
+            // pack finds the result of one of the tile's first few pieces of a bin in its LDS staging area: say where
+            const bool st = bin == JTK_BIN_TINY ? i < (uint32_t)JTK_PACK_TINY : i < (uint32_t)JTK_PACK_CAP(bin);
+            const uint32_t idx = (st && bin != JTK_BIN_TINY) ? (uint32_t)JTK_PACK_OFF(bin) + i : i;
+            entry = JTK_PL_HARD | (st ? JTK_PL_STAGED : 0u) | ((uint32_t)bin << JTK_PL_BIN_SHIFT) | (idx << JTK_PL_QI_SHIFT) | (uint32_t)s;
         }
         plist[k] = entry;
     };
@@ -572,7 +582,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     // piece's bytes (so that the merge kernel reads 16 dense bytes per piece instead of a 64-byte slab of the text).
     // A tile with few merge pieces (ordinary text) leaves that to wave 0; the other waves are done and leave, so
     // their slots go to the next tile's workgroup while the atomic is in flight.
-    const uint32_t n_queued = s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4] + s_qn[JTK_BIN_TINY];
+    const uint32_t n_queued = s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4] + s_qn[5] + s_qn[6] + s_qn[JTK_BIN_TINY];
     const bool all_waves = n_queued > 64u;                           // workgroup-uniform
     if (!all_waves && wv != 0) return;
     if (wv == 0) {
@@ -592,19 +602,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     if (all_waves) __syncthreads(); else wave_lds_fence();
     const int nthr = all_waves ? 256 : WAVE, me = all_waves ? tid : lane;
-    {   // bin 0: bytes + meta
-        const uint32_t nq0 = s_qn[0];
-        const int64_t qbase = (tile % JTK_Q_SHARDS) * w.q_cap[0] + s_qb[0];
+#pragma unroll
+    for (int q = 0; q < JTK_NBINS_BYTES; q++) {   // bins of <= 16 bytes: bytes + meta
+        const uint32_t nq0 = s_qn[q];
+        const int64_t qbase = (tile % JTK_Q_SHARDS) * w.q_cap[q] + s_qb[q];
         const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
         for (uint32_t i = (uint32_t)me; i < nq0; i += (uint32_t)nthr) {
-            const uint32_t e = s_q[Q_OFF0 + i];
+            const uint32_t e = s_q[q_off(q) + i];
             const uint32_t off = e & 2047u;
             const int a = (int)(off >> 2);
             const uint32_t sh = off & 3u;
             const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2], w3 = tw[a + 3], w4 = tw[a + 4];
-            w.qd[0][qbase + i] = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+            w.qd[q][qbase + i] = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
                                             __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
-            w.qm[0][qbase + i] = (uint64_t)(B + off) | ((uint64_t)((e >> 11) & 255u) << JTK_QE_LEN_SHIFT);
+            w.qm[q][qbase + i] = (uint64_t)(B + off) | ((uint64_t)((e >> 11) & 255u) << JTK_QE_LEN_SHIFT);
         }
     }
     {   // tiny pieces: position, length and the 2..3 bytes in one word
@@ -612,7 +623,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         uint64_t* dst = w.qt + (tile % JTK_Q_SHARDS) * w.qt_cap + s_qb[JTK_BIN_TINY];
         const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
         for (uint32_t i = (uint32_t)me; i < nq5; i += (uint32_t)nthr) {
-            const uint32_t e = s_q[Q_OFF5 + i];
+            const uint32_t e = s_q[q_off(JTK_BIN_TINY) + i];
             const uint32_t off = e & 2047u, len = ((e >> 11) & 255u) + 1u;
             const int a = (int)(off >> 2);
             uint32_t by = __builtin_amdgcn_alignbyte(tw[a + 1], tw[a], off & 3u) & 0xFFFFFFu;
@@ -621,8 +632,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         }
     }
 #pragma unroll
-    for (int q = 1; q < JTK_NBINS; q++) {
-        const int qoff = q == 1 ? Q_OFF1 : q == 2 ? Q_OFF2 : q == 3 ? Q_OFF3 : Q_OFF4;
+    for (int q = JTK_NBINS_BYTES; q < JTK_NBINS; q++) {
+        const int qoff = q_off(q);
         const uint32_t nq_q = s_qn[q];
         uint64_t* dst = w.qm[q] + (tile % JTK_Q_SHARDS) * w.q_cap[q] + s_qb[q];
         for (uint32_t i = (uint32_t)me; i < nq_q; i += (uint32_t)nthr) {
@@ -808,25 +819,21 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
         bool have = qi < count;
         uint64_t meta = 0;
         uint4 by = make_uint4(0, 0, 0, 0);
-        if (have) { meta = qm[qi]; if (BIN == 0) by = qd[qi]; }
-        if (BIN > 0 && (meta & JTK_QE_DONE)) have = false;          // a table entry of > 16 bytes: result and count are in place
+        if (have) { meta = qm[qi]; if (BIN < JTK_NBINS_BYTES) by = qd[qi]; }
+        if (BIN >= JTK_NBINS_BYTES && (meta & JTK_QE_DONE)) have = false;     // a table entry of > 16 bytes: result and count are in place
         const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
         const int len = have ? (int)((meta >> JTK_QE_LEN_SHIFT) & 255u) + 1 : 0;
         M alive;
-        if (BIN == 0) {
+        if (BIN < JTK_NBINS_BYTES) {
             const uint32_t d4[4] = {by.x, by.y, by.z, by.w};
             uint32_t b[17];
 #pragma unroll
             for (int j = 0; j < 16; j++) b[j] = (d4[j >> 2] >> (8 * (j & 3))) & 255u;
             b[16] = 0;
-            // the wave's longest piece picks the unrolled variant (wave-uniform)
-            if (!__ballot(len > 8)) {
-                if (!__ballot(len > 4)) { uint32_t c[5]; for (int j = 0; j < 5; j++) c[j] = b[j]; alive = lean_piece16<4, THREADS>(L, id, rk, c, len, t); }
-                else { uint32_t c[9]; for (int j = 0; j < 9; j++) c[j] = b[j]; alive = lean_piece16<8, THREADS>(L, id, rk, c, len, t); }
-            } else {
-                if (!__ballot(len > 12)) { uint32_t c[13]; for (int j = 0; j < 13; j++) c[j] = b[j]; alive = lean_piece16<12, THREADS>(L, id, rk, c, len, t); }
-                else alive = lean_piece16<16, THREADS>(L, id, rk, b, len, t);
-            }
+            // the bin's longest piece picks the unrolled variant: 8, 12 or 16 slots
+            if (BIN == 0) { uint32_t c[9]; for (int j = 0; j < 9; j++) c[j] = b[j]; alive = lean_piece16<8, THREADS>(L, id, rk, c, len, t); }
+            else if (BIN == 1) { uint32_t c[13]; for (int j = 0; j < 13; j++) c[j] = b[j]; alive = lean_piece16<12, THREADS>(L, id, rk, c, len, t); }
+            else alive = lean_piece16<16, THREADS>(L, id, rk, b, len, t);
         } else {
             // the piece's bytes from the text: the aligned 16-byte words that cover it are parked in the (idle) key slots,
             // then expanded in two passes (byte pairs into the id slots; ids and keys from those)
@@ -1444,12 +1451,13 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = *w.n_giant;
     __syncthreads();
     // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
-    const uint32_t n0 = s_count[0], n1 = s_count[1], n2 = s_count[2];
-    const bool w0 = kq * (uint32_t)ML_THREADS < n0, w1 = kq * (uint32_t)(ML_THREADS / 2) < n1, w2 = kq * (uint32_t)(ML_THREADS / 4) < n2;
-    const bool rest = (s_count[3] | s_count[4] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
+    const uint32_t n0 = s_count[0], n1 = s_count[1], n2 = s_count[2], n3 = s_count[3], n4 = s_count[4];
+    const bool w0 = kq * (uint32_t)ML_THREADS < n0, w1 = kq * (uint32_t)ML_THREADS < n1, w2 = kq * (uint32_t)ML_THREADS < n2,
+               w3 = kq * (uint32_t)(ML_THREADS / 2) < n3, w4 = kq * (uint32_t)(ML_THREADS / 4) < n4;
+    const bool rest = (s_count[5] | s_count[6] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
     const uint32_t nt5 = s_ntiny;
     const bool w5 = kq * (uint32_t)ML_THREADS < nt5;
-    if (!(w0 || w1 || w2 || w5 || rest)) return;
+    if (!(w0 || w1 || w2 || w3 || w4 || w5 || rest)) return;
     s_bpbits[tid] = t.bp.bits[tid];
     s_bpcum[tid] = t.bp.cum[tid];
     for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
@@ -1457,13 +1465,17 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     __syncthreads();
     const LeanLds LL{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
     if (w5) tiny_bin<ML_THREADS>(w, LL, nt5);                    // (no parts in LDS: no barrier needed before the next phase)
+    // (the three classes of <= 16 bytes share one LDS layout, [16 slots][1024 lanes], and a lane uses only its own column:
+    // no barrier between them)
     if (w0) lean_bin<16, ML_THREADS, 0>(w, t, LL, n0);
-    if (w1) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 1>(w, t, LL, n1); }
-    if (w2) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 2>(w, t, LL, n2); }
+    if (w1) lean_bin<16, ML_THREADS, 1>(w, t, LL, n1);
+    if (w2) lean_bin<16, ML_THREADS, 2>(w, t, LL, n2);
+    if (w3) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 3>(w, t, LL, n3); }
+    if (w4) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 4>(w, t, LL, n4); }
     if (!rest) return;
     const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
-    if (s_count[3]) { __syncthreads(); merge_bin<128, 128, 3>(w, t, L); }
-    if (s_count[4]) { __syncthreads(); merge_bin<256, 64, 4>(w, t, L); }
+    if (s_count[5]) { __syncthreads(); merge_bin<128, 128, 5>(w, t, L); }
+    if (s_count[6]) { __syncthreads(); merge_bin<256, 64, 6>(w, t, L); }
     // pieces of 257..512 bytes: every wave of the grid takes pieces, parts in its own 2 x 512 words
     const uint32_t wv = (uint32_t)tid >> 6;
     if (s_count[JTK_NBINS]) {
@@ -1574,24 +1586,15 @@ template <int I> __device__ __forceinline__ uint32_t res_tok(const uint4& r) {
 #ifndef JTK_PACK_STAGE
 #define JTK_PACK_STAGE 768
 #endif
-#ifndef JTK_PACK_Q0
-#define JTK_PACK_Q0 64
-#endif
-#ifndef JTK_PACK_QH
-#define JTK_PACK_QH 16
-#endif
-#ifndef JTK_PACK_QT
-#define JTK_PACK_QT 128
-#endif
 constexpr int PACK_STAGE = JTK_PACK_STAGE;     // tokens of a tile assembled in LDS (ordinary text: a few hundred)
-constexpr int PQ0 = JTK_PACK_Q0, PQH = JTK_PACK_QH, PQT = JTK_PACK_QT;   // staged merge results: bin 0, bins 1..4 each, tiny pieces
+constexpr int PQT = JTK_PACK_TINY;
 
 __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     // ONE WAVE PER TILE, no workgroup barriers.  A wave keeps a whole tile in flight: 8 list entries per lane, the head
     // of the tile's merge results (they are dense: the tile's slice of each bin's queue) and the document mask are all
     // requested before the first wait.  The tile's tokens are assembled in LDS (the few multi-token pieces make sparse
     // writes, cheap there and expensive in memory) and leave in full 256-byte stores.
-    __shared__ uint4 s_qe[PQ0 + 4 * PQH];
+    __shared__ uint4 s_qe[JTK_PACK_SLOTS];
     __shared__ uint2 s_qt[PQT];                 // staged results of the tile's tiny pieces
     __shared__ uint64_t s_dm[TW];
     __shared__ uint32_t s_out[PACK_STAGE];
@@ -1612,16 +1615,20 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
         const int64_t dwd = (B >> 6) + lane;
         s_dm[lane] = (dwd < w.n_words) ? w.docmask[dwd] : 0ull;
     }
-    // the tile's merge results: the first 64 of bin 0 and the first 16 of bins 1..4 are staged, others are read on demand
+    // the tile's merge results: the head of its slice of every bin's queue is staged (one load per lane for the three
+    // classes of <= 16 bytes, one more for the longer bins if the tile has any), the rest is read on demand
     const int64_t shard = tile % JTK_Q_SHARDS;
-    const uint32_t qb0 = (uint32_t)__shfl((int)meta, 0), nq0 = (uint32_t)__shfl((int)meta, 8);
-    const uint4* const res0 = w.qd[0] + shard * w.q_cap[0] + qb0;
-    if ((uint32_t)lane < nq0 && lane < PQ0) s_qe[lane] = res0[lane];
-    const uint32_t nq_hi = (uint32_t)__shfl((int)meta, 9) | (uint32_t)__shfl((int)meta, 10) | (uint32_t)__shfl((int)meta, 11) | (uint32_t)__shfl((int)meta, 12);
+    {
+        const int bl = lane < 32 ? 0 : lane < 48 ? 1 : 2, il = lane < 32 ? lane : lane < 48 ? lane - 32 : lane - 48;
+        const uint32_t qbv = (uint32_t)__shfl((int)meta, bl), nqv = (uint32_t)__shfl((int)meta, 8 + bl);
+        const uint4* src = (bl == 0 ? w.qd[0] + shard * w.q_cap[0] : bl == 1 ? w.qd[1] + shard * w.q_cap[1] : w.qd[2] + shard * w.q_cap[2]) + qbv;
+        if ((uint32_t)il < nqv) s_qe[lane] = src[il];
+    }
+    const uint32_t nq_hi = (uint32_t)__shfl((int)meta, 11) | (uint32_t)__shfl((int)meta, 12) | (uint32_t)__shfl((int)meta, 13) | (uint32_t)__shfl((int)meta, 14);
     if (nq_hi) {                                                          // wave-uniform; rare in ordinary text
-        const int bq = 1 + (lane >> 4);
+        const int bq = 3 + ((lane >> 3) & 3), il = lane & 7;
         const uint32_t qb = (uint32_t)__shfl((int)meta, bq), nq = (uint32_t)__shfl((int)meta, 8 + bq);
-        if ((uint32_t)(lane & 15) < nq && (lane & 15) < PQH) s_qe[PQ0 + (bq - 1) * PQH + (lane & 15)] = (w.qd[bq] + shard * w.q_cap[bq] + qb)[lane & 15];
+        if (lane < 32 && (uint32_t)il < nq) s_qe[64 + lane] = (w.qd[bq] + shard * w.q_cap[bq] + qb)[il];
     }
     const uint32_t qb5 = (uint32_t)__shfl((int)meta, JTK_BIN_TINY), nq5 = (uint32_t)__shfl((int)meta, 8 + JTK_BIN_TINY);
     const uint2* const res5 = reinterpret_cast<const uint2*>(w.qt + shard * w.qt_cap + qb5);
@@ -1641,8 +1648,8 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
         const uint32_t bin = (ej >> JTK_PL_BIN_SHIFT) & 7u, qi = (ej >> JTK_PL_QI_SHIFT) & 1023u;
         const bool queued = hard && !(ej & JTK_PL_NOQUEUE);
         const bool tinyp = bin == JTK_BIN_TINY;
-        const bool staged = queued && (bin == 0 ? qi < (uint32_t)PQ0 : tinyp ? qi < (uint32_t)PQT : qi < (uint32_t)PQH);
-        const uint32_t sidx = staged && !tinyp ? (bin == 0 ? qi : (uint32_t)PQ0 + (bin - 1u) * (uint32_t)PQH + qi) : 0u;
+        const bool staged = queued && (ej & JTK_PL_STAGED) != 0u;       // (piece_resolve knew: qi is the staging slot then)
+        const uint32_t sidx = staged && !tinyp ? qi : 0u;
         uint4 qe = s_qe[sidx];
         if (__ballot(queued && tinyp)) { if (staged && tinyp) qe = tiny_word(s_qt[qi]); }
         uint32_t c = valid ? (hard ? (qe.w >> 24) + 1u : 1u) : 0u;
@@ -1754,7 +1761,7 @@ __device__ uint32_t long_lookup(const JtkWork& w, const JtkDeviceTables& t, int6
 
 __global__ void __launch_bounds__(256) k_long_shortcut(JtkWork w, JtkDeviceTables t) {
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
-    for (int bin = 1; bin < JTK_NBINS; bin++) {
+    for (int bin = JTK_NBINS_BYTES; bin < JTK_NBINS; bin++) {
         for (int shard = 0; shard < JTK_Q_SHARDS; shard++) {
             const uint32_t count = w.q_count[bin * JTK_Q_SHARDS + shard];
             uint64_t* qm = w.qm[bin] + (int64_t)shard * w.q_cap[bin];
