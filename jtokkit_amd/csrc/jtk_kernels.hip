@@ -662,7 +662,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 // Bins 1, 2 (<= 32, <= 64 bytes; rare): bytes from the text.  Token counts are summed per tile into tile_tot.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t KL_NONE = 0xFFFFFFFFu;
-constexpr int ML_THREADS = 1024;
+#ifndef JTK_ML_THREADS
+#define JTK_ML_THREADS 1024
+#endif
+constexpr int ML_THREADS = JTK_ML_THREADS;       // lanes (= pieces in flight) per workgroup; 16 part slots x 8 bytes of LDS each
+constexpr int ML_WORDS = 16 * ML_THREADS;
 constexpr int ML_WGS_PER_SHARD = 4;
 
 struct LeanLds {
@@ -1429,8 +1433,8 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
 // on ordinary text the later phases find empty queues and cost nothing.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint32_t s_id[16384];
-    __shared__ uint32_t s_rk[16384];
+    __shared__ uint32_t s_id[ML_WORDS];
+    __shared__ uint32_t s_rk[ML_WORDS];
     __shared__ uint64_t s_bpbits[1024];
     __shared__ uint32_t s_bpranks[JTK_BP_MAX];
     __shared__ uint16_t s_bpcum[1024];
@@ -1458,8 +1462,7 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     const uint32_t nt5 = s_ntiny;
     const bool w5 = kq * (uint32_t)ML_THREADS < nt5;
     if (!(w0 || w1 || w2 || w3 || w4 || w5 || rest)) return;
-    s_bpbits[tid] = t.bp.bits[tid];
-    s_bpcum[tid] = t.bp.cum[tid];
+    for (int i = tid; i < 1024; i += ML_THREADS) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
     if (tid < 256) s_brank[tid] = t.byte_rank[tid];
     __syncthreads();
@@ -1474,13 +1477,14 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     if (w4) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 4>(w, t, LL, n4); }
     if (!rest) return;
     const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
-    if (s_count[5]) { __syncthreads(); merge_bin<128, 128, 5>(w, t, L); }
-    if (s_count[6]) { __syncthreads(); merge_bin<256, 64, 6>(w, t, L); }
+    if (s_count[5]) { __syncthreads(); merge_bin<128, ML_WORDS / 128, 5>(w, t, L); }
+    if (s_count[6]) { __syncthreads(); merge_bin<256, ML_WORDS / 256, 6>(w, t, L); }
     // pieces of 257..512 bytes: every wave of the grid takes pieces, parts in its own 2 x 512 words
     const uint32_t wv = (uint32_t)tid >> 6;
     if (s_count[JTK_NBINS]) {
         __syncthreads();
-        merge_long<JTK_MID_CAP>(w, t, s_id + wv * JTK_MID_CAP, s_rk + wv * JTK_MID_CAP, blockIdx.x * 16u + wv, gridDim.x * 16u);
+        merge_long<JTK_MID_CAP>(w, t, s_id + wv * JTK_MID_CAP, s_rk + wv * JTK_MID_CAP, blockIdx.x * (uint32_t)(ML_THREADS / 64) + wv,
+                                gridDim.x * (uint32_t)(ML_THREADS / 64));
     }
     // pieces of 513..8192 bytes: one wave per workgroup, parts in 2 x 8192 words
     if (s_count[JTK_NBINS + 1]) {
