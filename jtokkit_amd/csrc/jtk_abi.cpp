@@ -269,16 +269,9 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
     if (const char* e = getenv("JTK_HOST_CHUNK_BYTES")) { const long long v = atoll(e); if (v >= (1 << 16)) b->host_chunk_bytes = v; }
     if (const char* e = getenv("JTK_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= MAX_SETS) b->n_sets = v; }
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result, sizeof(JtkResult), hipHostMallocDefault);
-    for (int k = 0; k < MAX_SETS && e == hipSuccess; k++) {
-        ChunkSet& cs = b->set[k];
-        e = hipStreamCreateWithFlags(&cs.stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&cs.ev_scan, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&cs.ev_done, hipEventDisableTiming);
-    }
+    // (the streams and events of the chunk pipeline are created by the first job that forks: a batch that only ever sees
+    // small single-chunk jobs -- one per caller thread in the per-call shape -- owns one stream, not six)
     if (e != hipSuccess) {
         jtk_batch_destroy(b);
         return fail(JTK_ERR_HIP, std::string("batch create: ") + hipGetErrorString(e));
@@ -473,8 +466,22 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         const size_t need = (size_t)n_chunks * N_STAGES * 2;
         while (b->prof_ev.size() < need) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); b->prof_ev.push_back(ev); }
     }
-    const bool fork = n_chunks > 1 || h_text != nullptr;
-    if (fork) HIP_TRY(hipEventRecord(b->ev_fork, s));
+    const bool fork = n_chunks > 1 || (h_text != nullptr && !(n_chunks == 1 && n_bytes <= SMALL_JOB_BYTES));
+    if (fork) {
+        if (!b->ev_fork) {
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming));
+            HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+        }
+        for (int k = 0; k < n_sets; k++) {
+            ChunkSet& cs = b->set[k];
+            if (cs.stream) continue;
+            HIP_TRY(hipStreamCreateWithFlags(&cs.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&cs.ev_scan, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&cs.ev_done, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(b->ev_fork, s));
+    }
     for (ChunkSet& cs : b->set) cs.used = false;
 
     if ((rc = ensure_pinned((void**)&b->h_info, &b->h_info_cap, ((size_t)n_chunks + 1) * 16, 0))) return rc;

@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 pass() {
   name=$1; shift
-  rocprofv3 --pmc "$@" -d $out/$name -o c --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-subrecords --serial $BENCH_ARGS > $out/$name.log 2>&1
+  rocprofv3 --pmc "$@" -d $out/$name -o c --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-subrecords --serial --gen-workers 1 $BENCH_ARGS > $out/$name.log 2>&1
   echo "pass $name done"
 }
 BENCH_ARGS="$*"

@@ -11,7 +11,9 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+if [ ! -s $out/bench_under_rocprof.json ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $root/bench.py --no-subrecords --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/kt.log
+fi
 cd $root
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 echo "kernel trace done"
