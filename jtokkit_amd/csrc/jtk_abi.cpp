@@ -126,6 +126,7 @@ struct jtk_batch {
 };
 
 #include "jtk_unicode_tables.h"
+#include "jtk_block_classify.h"
 
 
 extern "C" {
@@ -234,6 +235,10 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     dt.bp.cum = (const uint16_t*)enc->bpcum.p;
     dt.bp.ranks = (const uint32_t*)enc->bpranks.p;
     dt.pair_in_token = (const uint32_t*)enc->pairin.p;
+    {
+        const JtkUcTables host_uc{jtk_uc_stage1_init, jtk_uc_stage2_init};
+        for (uint32_t b = 0; b < 256; b++) if (jtk_lead_all_letters(host_uc, b)) dt.lead_letters[b >> 5] |= 1u << (b & 31);
+    }
     dt.kind = pattern_kind;
     dt.n_specials = n_specials;
     for (int i = 0; i < n_specials; i++) {

@@ -2,11 +2,12 @@
 //
 // jtk_split_masks.h consumes 64-bit masks per block.  Producing them with one lane per byte and
 // __ballot costs a wave-instruction per mask per block; here each lane classifies its own block:
-//   1. every byte is looked up in a 256-entry table of 16-bit flag codes (ASCII bytes are fully
-//      classified by it; bytes >= 0x80 only get their UTF-8 role),
-//   2. the 64 codes are turned into 16 masks by 8x8 bit-matrix transposes (no per-bit loops),
-//   3. characters outside ASCII are decoded and classified one by one (lead bytes only) and their
-//      class is copied to all their bytes.
+//   1. every byte is looked up in a 256-entry table of 16 flags (ASCII bytes are fully classified by
+//      it; bytes >= 0x80 get their UTF-8 role and, for lead bytes, "every character is a letter"),
+//   2. the table entries are laid out so that a shift-or per text byte accumulates the 16 masks
+//      (no per-bit loops, no bit transposes); a 4x4 byte transpose per 32 bytes puts them in place,
+//   3. the remaining characters outside ASCII are decoded and classified one by one (lead bytes
+//      only) and their class is copied to all their bytes.
 // Host/device shared so that it can be checked against the per-byte construction on the CPU.
 #ifndef JTK_BLOCK_CLASSIFY_H
 #define JTK_BLOCK_CLASSIFY_H
@@ -19,7 +20,8 @@ enum : uint32_t {
     JTK_F_L = 1u << 0, JTK_F_N = 1u << 1, JTK_F_W = 1u << 2, JTK_F_NL = 1u << 3, JTK_F_SP = 1u << 4, JTK_F_AP = 1u << 5,
     JTK_F_CONT = 1u << 6, JTK_F_LEAD = 1u << 7,          // LEAD: first byte of a non-ASCII character
     JTK_F_S1 = 1u << 8, JTK_F_RV = 1u << 9, JTK_F_E = 1u << 10, JTK_F_LL = 1u << 11, JTK_F_C5 = 1u << 12, JTK_F_BF = 1u << 13,
-    JTK_F_LT = 1u << 14                                   // a byte a special-token literal starts with (set by the kernel from the encoding's literals)
+    JTK_F_LT = 1u << 14,                                  // a byte a special-token literal starts with (set by the kernel from the encoding's literals)
+    JTK_F_ULL = 1u << 15                                  // lead byte of characters that are all letters (jtk_lead_all_letters; set by the kernel)
 };
 
 JTK_HD uint32_t jtk_byte_code(uint32_t b, bool case_insensitive) {
@@ -45,87 +47,145 @@ JTK_HD uint32_t jtk_byte_code(uint32_t b, bool case_insensitive) {
     return c;
 }
 
-// 8x8 bit-matrix transpose: bit (8*r + c) of the result = bit (8*c + r) of x
-JTK_HD uint64_t jtk_transpose8x8(uint64_t x) {
-    uint64_t t;
-    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x ^= t ^ (t << 7);
-    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
-    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
-    return x;
+// The table the kernel reads: one 16-byte entry per byte value, flag f of the 16-bit code as bit 0 of byte (f & 3) of word
+// (f >> 2).  Shifting an accumulator left by one and OR-ing the entry in, for the 8 bytes of a group from the last to the
+// first, leaves in byte q of accumulator word w the 8-bit mask of flag 4w + q over the group: no per-bit work, no bit
+// transposes; one 16-byte LDS read and four shift-or instructions per text byte.
+struct JtkCode4 { uint32_t x, y, z, w; };
+JTK_HD JtkCode4 jtk_code4(uint32_t code) {
+    JtkCode4 e;
+    e.x = (code & 1u) | ((code >> 1) & 1u) << 8 | ((code >> 2) & 1u) << 16 | ((code >> 3) & 1u) << 24;
+    e.y = ((code >> 4) & 1u) | ((code >> 5) & 1u) << 8 | ((code >> 6) & 1u) << 16 | ((code >> 7) & 1u) << 24;
+    e.z = ((code >> 8) & 1u) | ((code >> 9) & 1u) << 8 | ((code >> 10) & 1u) << 16 | ((code >> 11) & 1u) << 24;
+    e.w = ((code >> 12) & 1u) | ((code >> 13) & 1u) << 8 | ((code >> 14) & 1u) << 16 | ((code >> 15) & 1u) << 24;
+    return e;
 }
 
-// d[0..15]: the block's 64 bytes, little-endian dwords.  codes: 256 x uint16 flag codes.
+// (a << 1) | e as ONE instruction the optimiser may not re-associate (it would otherwise gather eight table entries into
+// or-trees per word and spill the other twelve bytes of each entry)
+JTK_HD uint32_t jtk_shl1_or(uint32_t a, uint32_t e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(r) : "v"(a), "v"(e));
+    return r;
+#else
+    return (a << 1) | e;
+#endif
+}
+
+// bytes of {hi, lo} picked by the four selector bytes of sel (0..3: lo, 4..7: hi) -- v_perm_b32
+JTK_HD uint32_t jtk_byteperm(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int q = 0; q < 4; q++) r |= (uint32_t)((v >> (8 * ((sel >> (8 * q)) & 7u))) & 255u) << (8 * q);
+    return r;
+#endif
+}
+
+// 4x4 byte transpose: g[i] byte q  ->  o[q] byte i
+JTK_HD void jtk_transpose4x4_bytes(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3, uint32_t (&o)[4]) {
+    const uint32_t t0 = jtk_byteperm(g1, g0, 0x05010400u), t1 = jtk_byteperm(g3, g2, 0x05010400u);
+    const uint32_t t2 = jtk_byteperm(g1, g0, 0x07030602u), t3 = jtk_byteperm(g3, g2, 0x07030602u);
+    o[0] = jtk_byteperm(t1, t0, 0x05040100u); o[1] = jtk_byteperm(t1, t0, 0x07060302u);
+    o[2] = jtk_byteperm(t3, t2, 0x05040100u); o[3] = jtk_byteperm(t3, t2, 0x07060302u);
+}
+
+// d[0..15]: the block's 64 bytes, little-endian dwords.  tab: 256 entries (jtk_code4 of the byte's flag code).
 // Fills the table-derived part of the masks (class bits of non-ASCII characters are still 0).
-// lead_out: mask of non-ASCII lead bytes.
-template <class CodeTab>
-JTK_HD void jtk_block_masks_ascii(const uint32_t (&d)[16], const CodeTab& codes, JtkBlk& k, uint64_t& lead_out, uint64_t& lt_out) {
-    uint64_t lo_m[8], hi_m[8];
-#pragma unroll
-    for (int f = 0; f < 8; f++) { lo_m[f] = 0; hi_m[f] = 0; }
+// lead_out: non-ASCII lead bytes; lt_out: bytes a special literal starts with; ull_out: lead bytes of characters that are
+// letters whatever their other bytes are.
+template <class Tab4>
+JTK_HD void jtk_block_masks_ascii(const uint32_t (&d)[16], const Tab4& tab, JtkBlk& k, uint64_t& lead_out, uint64_t& lt_out,
+                                  uint64_t& ull_out) {
+    uint32_t a[8][4];
 #pragma unroll
     for (int g = 0; g < 8; g++) {
-        uint64_t xl = 0, xh = 0;
+        uint32_t a0, a1, a2, a3;
+        {
+            const JtkCode4 e = tab[d[2 * g + 1] >> 24];
+            a0 = e.x; a1 = e.y; a2 = e.z; a3 = e.w;
+        }
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 6; q >= 0; q--) {
             const uint32_t b = (d[2 * g + (q >> 2)] >> (8 * (q & 3))) & 255u;
-            const uint32_t c = codes[b];
-            xl |= (uint64_t)(c & 255u) << (8 * q);
-            xh |= (uint64_t)(c >> 8) << (8 * q);
+            const JtkCode4 e = tab[b];
+            a0 = jtk_shl1_or(a0, e.x); a1 = jtk_shl1_or(a1, e.y); a2 = jtk_shl1_or(a2, e.z); a3 = jtk_shl1_or(a3, e.w);
         }
-        const uint64_t yl = jtk_transpose8x8(xl), yh = jtk_transpose8x8(xh);
-#pragma unroll
-        for (int f = 0; f < 8; f++) {
-            lo_m[f] |= ((yl >> (8 * f)) & 255ull) << (8 * g);
-            if (f < 7) hi_m[f] |= ((yh >> (8 * f)) & 255ull) << (8 * g);
-        }
+        a[g][0] = a0; a[g][1] = a1; a[g][2] = a2; a[g][3] = a3;
     }
-    k.L = lo_m[0]; k.N = lo_m[1]; k.W = lo_m[2]; k.NL = lo_m[3]; k.SP = lo_m[4]; k.AP = lo_m[5]; k.CONT = lo_m[6];
-    lead_out = lo_m[7];
-    k.S1 = hi_m[0]; k.RV = hi_m[1]; k.E = hi_m[2]; k.LL = hi_m[3]; k.C5 = hi_m[4]; k.BF = hi_m[5];
-    lt_out = hi_m[6];
-}
-template <class CodeTab>
-JTK_HD void jtk_block_masks_ascii(const uint32_t (&d)[16], const CodeTab& codes, JtkBlk& k, uint64_t& lead_out) {
-    uint64_t lt;
-    jtk_block_masks_ascii(d, codes, k, lead_out, lt);
+    uint64_t m[16];
+#pragma unroll
+    for (int wd = 0; wd < 4; wd++) {
+        uint32_t lo[4], hi[4];
+        jtk_transpose4x4_bytes(a[0][wd], a[1][wd], a[2][wd], a[3][wd], lo);
+        jtk_transpose4x4_bytes(a[4][wd], a[5][wd], a[6][wd], a[7][wd], hi);
+#pragma unroll
+        for (int q = 0; q < 4; q++) m[4 * wd + q] = ((uint64_t)hi[q] << 32) | lo[q];
+    }
+    k.L = m[0]; k.N = m[1]; k.W = m[2]; k.NL = m[3]; k.SP = m[4]; k.AP = m[5]; k.CONT = m[6];
+    lead_out = m[7];
+    k.S1 = m[8]; k.RV = m[9]; k.E = m[10]; k.LL = m[11]; k.C5 = m[12]; k.BF = m[13];
+    lt_out = m[14];
+    ull_out = m[15];
 }
 
-// Non-ASCII characters that START in this block: decode (Txt gives byte(p) for any p), classify, and
-// give the class to all bytes of the character that lie inside the block.  Returns in spill_cls the
-// class of a character that runs over the block's end (or JTK_CLS_O) for the next block.
-template <class Txt>
-JTK_HD void jtk_block_fix_nonascii(const Txt& txt, const JtkUcTables& uc, int64_t p0, uint64_t lead, JtkBlk& k,
+// Is every character whose UTF-8 form starts with this lead byte a letter?  (CJK ideographs U+5000-8FFF, Hangul
+// U+B000-CFFF, basic Cyrillic, ...: computed from the class table, host side, once per encoding.)
+inline bool jtk_lead_all_letters(const JtkUcTables& uc, uint32_t b) {
+    uint32_t lo, hi;
+    if (b >= 0xC2u && b <= 0xDFu) { lo = (b & 0x1Fu) << 6; hi = lo + 63u; }
+    else if (b == 0xE0u) { lo = 0x800u; hi = 0xFFFu; }
+    else if (b == 0xEDu) { lo = 0xD000u; hi = 0xD7FFu; }              // surrogates have no UTF-8 form
+    else if (b >= 0xE1u && b <= 0xEFu) { lo = (b & 0x0Fu) << 12; hi = lo + 0xFFFu; }
+    else if (b == 0xF0u) { lo = 0x10000u; hi = 0x3FFFFu; }
+    else if (b >= 0xF1u && b <= 0xF3u) { lo = (b & 7u) << 18; hi = lo + 0x3FFFFu; }
+    else if (b == 0xF4u) { lo = 0x100000u; hi = 0x10FFFFu; }
+    else return false;
+    for (uint32_t cp = lo; cp <= hi; cp++) if (jtk_class_of_cp(uc, cp) != JTK_CLS_L) return false;
+    return true;
+}
+
+// x and the continuation bytes that directly follow each of its bits (at most 3)
+JTK_HD uint64_t jtk_with_cont_bytes(uint64_t x, uint64_t cont) {
+    const uint64_t c1 = (x << 1) & cont, c2 = (c1 << 1) & cont, c3 = (c2 << 1) & cont;
+    return x | c1 | c2 | c3;
+}
+
+// Non-ASCII characters that START in this block.  Leads in `ull` are letters without a look at the other bytes; the
+// others are decoded (txt.word(j): the 4 bytes that start at byte j of the block, zero beyond the text) and classified
+// one by one.  A character's class goes to its lead and the continuation bytes that directly follow it inside the
+// block.  spill_cls: the class of a character that runs up to the block's last byte (for the leading continuation
+// bytes of the next block; if the character ended there the next block has none), else JTK_CLS_O.
+template <class Txt4>
+JTK_HD void jtk_block_fix_nonascii(const Txt4& txt, const JtkUcTables& uc, uint64_t lead, uint64_t ull, JtkBlk& k,
                                    uint32_t& spill_cls) {
-    spill_cls = JTK_CLS_O;
-    for (uint64_t m = lead; m;) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int j = __ffsll((unsigned long long)m) - 1;
-#else
-        const int j = __builtin_ctzll(m);
-#endif
+    uint64_t c0 = ull & lead, c1 = 0;                                  // class bits 0 / 1 at the lead positions
+    for (uint64_t m = lead & ~ull; m;) {
+        const int j = jtk_ctz64(m);
         m &= m - 1;
-        const int64_t p = p0 + j;
-        const uint32_t b0 = txt.byte(p);
-        uint32_t cp, n;
-        if (b0 < 0xE0u) { cp = ((b0 & 0x1Fu) << 6) | (txt.byte(p + 1) & 0x3Fu); n = 2; }
-        else if (b0 < 0xF0u) { cp = ((b0 & 0x0Fu) << 12) | ((txt.byte(p + 1) & 0x3Fu) << 6) | (txt.byte(p + 2) & 0x3Fu); n = 3; }
-        else { cp = ((b0 & 0x07u) << 18) | ((txt.byte(p + 1) & 0x3Fu) << 12) | ((txt.byte(p + 2) & 0x3Fu) << 6) | (txt.byte(p + 3) & 0x3Fu); n = 4; }
-        // CJK ideographs (incl. extension A) and Hangul syllables are letters throughout (Unicode 13: U+3400-4DBF,
-        // U+4E00-9FFC, U+AC00-D7A3 are all Lo); everything else goes through the two-stage table
-        uint32_t cls;
-        if ((cp - 0x3400u) <= (0x4DBFu - 0x3400u) || (cp - 0x4E00u) <= (0x9FFCu - 0x4E00u) || (cp - 0xAC00u) <= (0xD7A3u - 0xAC00u)) cls = JTK_CLS_L;
-        else cls = jtk_class_of_cp(uc, cp);
-        // the character's bytes: the lead and the continuation bytes that directly follow it (at most n-1)
-        uint64_t bytes = 1ull << j;
-        for (uint32_t q = 1; q < n; q++) {
-            const int jj = j + (int)q;
-            if (jj < 64) { if ((k.CONT >> jj) & 1ull) bytes |= 1ull << jj; else break; }
-        }
-        if (cls == JTK_CLS_L) k.L |= bytes;
-        else if (cls == JTK_CLS_N) k.N |= bytes;
-        else if (cls == JTK_CLS_W) k.W |= bytes;
-        if (j + (int)n > 64) spill_cls = cls;
+        const uint32_t w = txt.word(j);
+        const uint32_t b0 = w & 255u, b1 = (w >> 8) & 0x3Fu, b2 = (w >> 16) & 0x3Fu, b3 = (w >> 24) & 0x3Fu;
+        uint32_t cp;
+        if (b0 < 0xE0u) cp = ((b0 & 0x1Fu) << 6) | b1;
+        else if (b0 < 0xF0u) cp = ((b0 & 0x0Fu) << 12) | (b1 << 6) | b2;
+        else cp = ((b0 & 0x07u) << 18) | (b1 << 12) | (b2 << 6) | b3;
+        const uint32_t cls = jtk_class_of_cp(uc, cp);
+        c0 |= (uint64_t)(cls & 1u) << j;
+        c1 |= (uint64_t)(cls >> 1) << j;
     }
+    spill_cls = JTK_CLS_O;
+    if (lead) {
+        const int jt = 63 - jtk_clz64(lead);
+        if (((~k.CONT >> jt) >> 1) == 0) spill_cls = (uint32_t)((c0 >> jt) & 1ull) | (uint32_t)((c1 >> jt) & 1ull) << 1;
+    }
+    c0 = jtk_with_cont_bytes(c0, k.CONT);
+    c1 = jtk_with_cont_bytes(c1, k.CONT);
+    k.L |= c0 & ~c1;
+    k.N |= c1 & ~c0;
+    k.W |= c0 & c1;
 }
 
 // Continuation bytes at the start of a block belong to a character that started in the previous block.

@@ -11,6 +11,15 @@
 #define JTK_HD inline
 #endif
 
+// bit scans (x != 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+JTK_HD int jtk_ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
+JTK_HD int jtk_clz64(uint64_t x) { return __clzll((long long)x); }
+#else
+JTK_HD int jtk_ctz64(uint64_t x) { return __builtin_ctzll(x); }
+JTK_HD int jtk_clz64(uint64_t x) { return __builtin_clzll(x); }
+#endif
+
 // ---- per-byte class codes produced by the classify stage ------------------------------------------
 // bits 0-1: class of the character this byte belongs to (continuation bytes inherit their lead's)
 enum : uint32_t {

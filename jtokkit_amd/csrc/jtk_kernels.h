@@ -70,6 +70,7 @@ struct JtkDeviceTables {
     const uint32_t* bp_rank;     // [65536]
     JtkBpLds bp;                 // the same, compressed (staged into LDS by bpe_merge)
     const uint32_t* pair_in_token;   // [2048] bit (b0 << 8 | b1): adjacent inside some table entry
+    uint32_t lead_letters[8];        // bit b: every character whose UTF-8 form starts with byte b is a letter (jtk_lead_all_letters)
     JtkLongTokTable longtok;         // table entries of > 16 bytes that merging does not reproduce (n == 0 for the shipped tables)
     int kind;
     int n_specials;

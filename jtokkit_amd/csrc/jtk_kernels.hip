@@ -165,12 +165,23 @@ struct GlobalText {
     __device__ uint32_t byte(int64_t p) const { return (p >= 0 && p < n) ? t[p] : 0u; }
 };
 
-// The lane's own 64-byte block (and the first bytes of the next lane's) from the LDS copy, [dword][lane].
-struct LdsBlockText {
-    const uint32_t* blk; int tid; int64_t p0;
-    __device__ uint32_t byte(int64_t p) const {
-        const uint32_t rel = (uint32_t)(p - p0);                       // 0 .. 66
-        return (blk[((rel >> 2) & 15u) * 256u + (uint32_t)tid + (rel >> 6)] >> (8u * (rel & 3u))) & 255u;
+constexpr int SPLIT_THREADS = 512;                     // the tables in LDS (24 KB) are shared by 8 waves
+
+// The 4 bytes that start at byte j of the lane's block, from the LDS copy [dword][lane]; row 16 is the next lane's first dword.
+struct LdsBlockWords {
+    const uint32_t* blk; int tid;
+    __device__ uint32_t word(int j) const {
+        const uint32_t a = (uint32_t)j >> 2;
+        const uint32_t lo = blk[a * SPLIT_THREADS + (uint32_t)tid], hi = blk[(a + 1u) * SPLIT_THREADS + (uint32_t)tid];
+        return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)j & 3u);
+    }
+};
+struct GlobalBlockWords {
+    const uint8_t* t; int64_t n, p0;
+    __device__ uint32_t word(int j) const {
+        uint32_t v = 0;
+        for (int r = 0; r < 4; r++) { const int64_t p = p0 + j + r; if (p >= 0 && p < n) v |= (uint32_t)t[p] << (8 * r); }
+        return v;
     }
 };
 
@@ -190,7 +201,7 @@ struct SlowWin {
 };
 
 constexpr int SPW = 62;                                // blocks a wave emits
-constexpr int SPLIT_BYTES = 4 * SPW * 64;              // bytes per workgroup
+constexpr int SPLIT_BYTES = (SPLIT_THREADS / 64) * SPW * 64;   // bytes per workgroup
 
 __device__ __forceinline__ uint64_t hi_from_prev_lane(uint64_t v) {      // only the top bits are consumed
     return (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1) << 32;
@@ -200,10 +211,10 @@ __device__ __forceinline__ uint64_t lo_from_next_lane(uint64_t v) {      // only
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_pretok_split(JtkWork w, JtkDeviceTables t) {
-    __shared__ uint16_t s_codes[256];          // per-byte flag codes (jtk_byte_code)
+__global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_pretok_split(JtkWork w, JtkDeviceTables t) {
+    __shared__ __attribute__((aligned(16))) JtkCode4 s_tab[256];   // per-byte flags, laid out for shift-or accumulation (jtk_block_classify.h)
     __shared__ uint32_t s_pin[2048];           // byte pairs that occur inside some table entry
-    __shared__ uint32_t s_blk[16 * 256 + 4];   // the lanes' blocks, [dword][lane] (staged only for text outside ASCII)
+    __shared__ uint32_t s_blk[17 * SPLIT_THREADS];   // the lanes' blocks, [dword][lane] (staged only for text outside ASCII)
     __shared__ __attribute__((aligned(4))) uint8_t s_uc1[JTK_UC_LDS_STAGE1];
     __shared__ uint32_t s_uc2[JTK_UC_LDS_STAGE2];
     __shared__ uint32_t s_uc_ready;
@@ -211,13 +222,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
     const int64_t n = w.n_bytes;
-    {
+    if (tid < 256) {
         uint32_t code = jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
         for (int q = 0; q < t.n_specials; q++) if (t.special[q][0] == (uint8_t)tid) code |= JTK_F_LT;
-        s_codes[tid] = (uint16_t)code;
+        if ((t.lead_letters[tid >> 5] >> (tid & 31)) & 1u) code |= JTK_F_ULL;
+        s_tab[tid] = jtk_code4(code);
     }
     if (tid == 0) s_uc_ready = 0;
-    for (int i = tid; i < 2048; i += 256) s_pin[i] = t.pair_in_token[i];
+    for (int i = tid; i < 2048; i += SPLIT_THREADS) s_pin[i] = t.pair_in_token[i];
     __syncthreads();
 
     // ---- this lane's block
@@ -236,8 +248,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
     }
     JtkBlk cu;
-    uint64_t lead, lt;
-    jtk_block_masks_ascii(d, s_codes, cu, lead, lt);
+    uint64_t lead, lt, ull;
+    jtk_block_masks_ascii(d, s_tab, cu, lead, lt, ull);
     // encode(): the special-token check of GptBytePairEncoding.java:52-56 rides along -- every '<' of the lanes that emit
     if (w.check_special && lane >= 1 && lane <= SPW) {
         for (uint64_t m = lt; m;) {
@@ -252,7 +264,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // chain is LDS reads, not global loads (the kernel runs at 2 waves per SIMD: nothing hides a global latency).
         uint32_t spill = JTK_CLS_O;
         const bool lds_ok = t.uc_stage1_len <= JTK_UC_LDS_STAGE1 && t.uc_stage2_words <= JTK_UC_LDS_STAGE2;
-        if (__ballot(lead != 0)) {                                    // per wave: no workgroup barrier on the ASCII path
+        // leads of characters that are letters whatever follows (CJK ideographs, Hangul, ...) need no decode: `ull`
+        if (__ballot((lead & ~ull) != 0)) {                           // per wave: no workgroup barrier on the ASCII path
             if (lds_ok) {
                 // the first wave that needs the table copies it; a wave that does not see the flag yet copies it again
                 // (same values: a benign race), so no barrier is needed
@@ -261,16 +274,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     for (uint32_t i = lane; i < t.uc_stage2_words; i += 64) s_uc2[i] = t.uc.stage2[i];
                 }
 #pragma unroll
-                for (int q = 0; q < 16; q++) s_blk[q * 256 + tid] = d[q];
+                for (int q = 0; q < 16; q++) s_blk[q * SPLIT_THREADS + tid] = d[q];
+                s_blk[16 * SPLIT_THREADS + tid] = (uint32_t)__shfl_down((int)d[0], 1);   // lane 63: its own (a halo block: only its low bits are used)
                 wave_lds_fence();
                 if (lane == 0) *(volatile uint32_t*)&s_uc_ready = 1u;
-                const LdsBlockText lt{s_blk, tid, p0};
+                const LdsBlockWords bw{s_blk, tid};
                 const JtkUcTables ucl{s_uc1, s_uc2};
-                jtk_block_fix_nonascii(lt, ucl, p0, lead, cu, spill);
+                jtk_block_fix_nonascii(bw, ucl, lead, ull, cu, spill);
             } else {
-                const GlobalText gt{w.text, n};
-                jtk_block_fix_nonascii(gt, t.uc, p0, lead, cu, spill);
+                const GlobalBlockWords bw{w.text, n, p0};
+                jtk_block_fix_nonascii(bw, t.uc, lead, ull, cu, spill);
             }
+        } else if (__ballot(lead != 0)) {
+            struct NoWords { __device__ uint32_t word(int) const { return 0u; } };
+            jtk_block_fix_nonascii(NoWords{}, t.uc, lead, ull, cu, spill);   // no lane of the wave decodes anything
         }
         uint32_t prev_spill = (uint32_t)__shfl_up((int)spill, 1);
         if (lane == 0) prev_spill = JTK_CLS_O;
@@ -287,8 +304,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
     // ---- the split rules for the whole block
     JtkBlk nx;
-    nx.L = nx.N = nx.NL = nx.SP = nx.AP = nx.S1 = nx.RV = nx.C5 = nx.BF = 0;
-    nx.W = lo_from_next_lane(cu.W); nx.DS = lo_from_next_lane(cu.DS); nx.CONT = lo_from_next_lane(cu.CONT);
+    nx.L = nx.N = nx.SP = nx.AP = nx.S1 = nx.RV = nx.C5 = nx.BF = 0;
+    nx.W = lo_from_next_lane(cu.W); nx.DS = lo_from_next_lane(cu.DS); nx.CONT = lo_from_next_lane(cu.CONT); nx.NL = lo_from_next_lane(cu.NL);
     nx.E = lo_from_next_lane(cu.E); nx.LL = lo_from_next_lane(cu.LL);
     JtkSplitCarry base;
     base.pL = hi_from_prev_lane(cu.L);   base.pN = hi_from_prev_lane(cu.N);   base.pW = hi_from_prev_lane(cu.W);
@@ -322,14 +339,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (!__ballot(changed)) break;
     }
 
-    // ---- per-position work that is not mask algebra: cl100k digit runs, and the rare slow positions
-    for (uint64_t m = nlanes; m;) {
-        const int j = jtk_ctz64(m);
-        m &= m - 1;
-        bool s2 = false;
-        const bool v = jtk_split_n_lane(cu, ncnt_in, nunk_in, j, s2);
-        if (s2) slow |= 1ull << j;
-        else if (v) ms |= 1ull << j;
+    // ---- cl100k digit runs (mask algebra unless the block has digits of several bytes), and the rare slow positions
+    if (KIND == JTK_PAT_CL100K && __ballot(nlanes != 0)) {
+        if ((cu.N & cu.CONT) == 0) {
+            uint64_t nslow;
+            ms |= jtk_split_n_block(cu, base.pN, ncnt_in, nunk_in, nslow);
+            slow |= nslow;
+            nlanes = 0;
+        }
+        for (uint64_t m = nlanes; m;) {
+            const int j = jtk_ctz64(m);
+            m &= m - 1;
+            bool s2 = false;
+            const bool v = jtk_split_n_lane(cu, ncnt_in, nunk_in, j, s2);
+            if (s2) slow |= 1ull << j;
+            else if (v) ms |= 1ull << j;
+        }
     }
     for (uint64_t m = slow; m;) {
         const int j = jtk_ctz64(m);
@@ -346,14 +371,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     // is exact, so blocks of short ASCII pieces (ordinary text) skip the 64 bitmap lookups.
     uint64_t cut = 0;
     if ((lead | cu.CONT) != 0 || __popcll(ms) < 6) {
-        uint32_t prev = prev_byte;
+        // pair (byte j-1, byte j) as an index: one byte permute; the bit accumulates from the top (alignbit), byte 0 ends at bit 0
+        uint32_t acc[2] = {0u, 0u};
 #pragma unroll
         for (int j = 0; j < 64; j++) {
-            const uint32_t cur = (d[j >> 2] >> (8 * (j & 3))) & 255u;
-            const uint32_t pi = (prev << 8) | cur;
-            cut |= (uint64_t)(((s_pin[pi >> 5] >> (pi & 31u)) & 1u) ^ 1u) << j;
-            prev = cur;
+            const int q = j >> 2, r = j & 3;
+            const uint32_t hi = d[q], lo = (j >= 4) ? d[q - 1] : (prev_byte << 24);
+            // index = prev << 8 | cur: byte 0 <- cur = hi byte r (selector 4 + r), byte 1 <- prev = hi byte r-1 or lo byte 3
+            const uint32_t sel = 0x0C0C0000u | (uint32_t)(r ? (4 + r - 1) : 3) << 8 | (uint32_t)(4 + r);
+            const uint32_t pi = __builtin_amdgcn_perm(hi, lo, sel);
+            const uint32_t in = s_pin[pi >> 5] >> (pi & 31u);
+            acc[j >> 5] = __builtin_amdgcn_alignbit(in, acc[j >> 5], 1);
         }
+        cut = ~(((uint64_t)acc[1] << 32) | acc[0]);
     }
 
     if (lane >= 1 && lane <= SPW) {
@@ -1888,8 +1918,8 @@ void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s) {
 }
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     const int64_t tiles = (w.n_bytes + 1 + SPLIT_BYTES - 1) / SPLIT_BYTES;
-    if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
-    else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(256), 0, s, w, t);
+    if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
+    else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
 }
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);

@@ -11,13 +11,6 @@
 
 #include "jtk_common.h"
 
-#if defined(__HIP_DEVICE_COMPILE__)
-JTK_HD int jtk_ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
-JTK_HD int jtk_clz64(uint64_t x) { return __clzll((long long)x); }
-#else
-JTK_HD int jtk_ctz64(uint64_t x) { return __builtin_ctzll(x); }
-JTK_HD int jtk_clz64(uint64_t x) { return __builtin_clzll(x); }
-#endif
 
 // ids[0..len): on entry the single-byte token id of every byte; on exit the token id at every
 // surviving part start and JTK_ID_DEAD elsewhere.  rk[0..len) is scratch.  1 <= len <= 64.

@@ -57,6 +57,28 @@ JTK_HD uint64_t jtk_fill_up(uint64_t seed, uint64_t through) {
     return x;
 }
 
+// bits of `seed` extended downwards: bit q is set when bit q+1 is and `through` has bit q
+JTK_HD uint64_t jtk_fill_down(uint64_t seed, uint64_t through) {
+    uint64_t x = seed, m = through;
+    x |= (x >> 1) & m;  m &= m >> 1;
+    x |= (x >> 2) & m;  m &= m >> 2;
+    x |= (x >> 4) & m;  m &= m >> 4;
+    x |= (x >> 8) & m;  m &= m >> 8;
+    x |= (x >> 16) & m; m &= m >> 16;
+    x |= (x >> 32) & m;
+    return x;
+}
+
+JTK_HD uint32_t jtk_fill_down32(uint32_t seed, uint32_t through) {
+    uint32_t x = seed, m = through;
+    x |= (x >> 1) & m;  m &= m >> 1;
+    x |= (x >> 2) & m;  m &= m >> 2;
+    x |= (x >> 4) & m;  m &= m >> 4;
+    x |= (x >> 8) & m;  m &= m >> 8;
+    x |= (x >> 16) & m;
+    return x;
+}
+
 JTK_HD void jtk_split_carry_init(JtkSplitCarry& c) {
     c.pL = c.pN = c.pW = c.pNL = c.pSP = c.pDS = c.pCONT = 0;
     c.pS1 = c.pRV = c.pE = c.pLL = c.pC5 = c.pBF = 0;
@@ -85,10 +107,38 @@ JTK_HD bool jtk_split_n_lane(const JtkBlk& cu, uint32_t ncnt, bool n_unknown, in
     return cnt % 3u == 0u;
 }
 
+// cl100k, all digits of the block at once when each is one byte ("\p{N}{1,3}": every third byte from the run's start; a run
+// that comes in from the previous block is `ncnt` digits (mod 3) into its phase).  pN_top: bit 63 = the byte before the
+// block is a digit.  Returns the piece starts among the digits; `slow` gets the digits of a run whose start is not visible.
+// Blocks with digits of several bytes (cu.N & cu.CONT) go through jtk_split_n_lane per digit instead.
+JTK_HD uint64_t jtk_split_n_block(const JtkBlk& cu, uint64_t pN_top, uint32_t ncnt, bool n_unknown, uint64_t& slow) {
+    const uint64_t notDS = ~cu.DS;
+    const uint64_t pN = (cu.N << 1) | (pN_top >> 63);
+    uint64_t S = cu.N & (~pN | cu.DS);
+    slow = 0;
+    if (cu.N & notDS & pN & 1ull) {                                     // the first byte goes on with a run
+        if (n_unknown) slow = jtk_fill_up(1ull, cu.N & notDS);
+        else {
+            const uint32_t r = ncnt == 0u ? 0u : 3u - ncnt;             // digits to the next piece start
+            const uint64_t req = (2ull << r) - 1ull;
+            if ((cu.N & req) == req && (cu.DS & req) == 0) S |= 1ull << r;
+        }
+    }
+    const uint64_t nn = cu.N & notDS;
+    uint64_t link = cu.N & (nn << 1) & (nn << 2) & (cu.N << 3) & notDS;   // q-3 .. q are digits of one run (q-3 may start a document)
+    uint64_t x = S;
+    x |= (x << 3) & link;   link &= link << 3;
+    x |= (x << 6) & link;   link &= link << 6;
+    x |= (x << 12) & link;  link &= link << 12;
+    x |= (x << 24) & link;  link &= link << 24;
+    x |= (x << 48) & link;
+    return x & notDS & ~slow;
+}
+
 // Piece-start mask of block `cu` for the positions that are decided by mask algebra; `slow` gets the
-// positions the caller must evaluate per lane (for cl100k it always contains the N lead bytes that
-// are not document starts: they go through jtk_split_n_lane).  `nx` supplies the next block (only
-// its low 4 bits are used).  Updates `cy` for the next block.
+// positions the caller must evaluate with jtk_is_piece_start_t, `nlanes` the digits it must pass through jtk_split_n_lane
+// (cl100k, only blocks with digits of several bytes; digit runs of ASCII are mask algebra).  `nx` supplies the next block (only
+// its low 32 bits are used).  Updates `cy` for the next block.
 template <int KIND>
 JTK_HD uint64_t jtk_split_block(const JtkBlk& cu, const JtkBlk& nx, JtkSplitCarry& cy, uint64_t& slow, uint64_t& nlanes) {
     constexpr bool cl = (KIND == JTK_PAT_CL100K);
@@ -128,7 +178,7 @@ JTK_HD uint64_t jtk_split_block(const JtkBlk& cu, const JtkBlk& nx, JtkSplitCarr
     // ---- numbers
     uint64_t Nms = 0;
     nlanes = 0;
-    if (cl) nlanes = cu.N & lead & notDS;                      // per lane: jtk_split_n_lane
+    if (cl) nlanes = cu.N & lead & notDS;                      // jtk_split_n_block / jtk_split_n_lane, once the carry is final
     else Nms = cu.N & lead & notDS & ~pN & ~pSP;
 
     // ---- whitespace
@@ -156,8 +206,25 @@ JTK_HD uint64_t jtk_split_block(const JtkBlk& cu, const JtkBlk& nx, JtkSplitCarr
         const uint64_t plain = wlead & ~cu.NL & ~pNL;          // neither a CR/LF nor right after one
         const uint64_t nl = wlead & cu.NL;
         const uint64_t afterNL = wlead & ~cu.NL & pNL;
+        // right after a CR/LF that was not swallowed: a start <=> no CR/LF remains in the rest of the whitespace run
+        // (jtk_split_rules.h: "\s*[\r\n]+" ends on the LAST CR/LF).  Byte q hears from byte q+1 when q is whitespace and q+1
+        // does not start a document; a run that leaves the block through whitespace that is not a CR/LF cannot be decided here.
+        const uint64_t cand = afterNL & ~pSW;
+        uint64_t undecided = 0;
         Wms = (plain & (~pW | ylo)) | (nl & ~SW & ~pW) | (afterNL & pSW);
-        slow = afterNL & ~pSW;
+        if (cand) {
+            const uint64_t thr = cu.W & ~nDS;
+            const uint64_t top = thr & ((nx.W & 1ull) << 63);           // the run goes on in the next block,
+            // whose first 32 bytes are visible: a CR/LF there that the run reaches, or the run's end
+            const uint32_t nxW = (uint32_t)nx.W, nxNL = (uint32_t)nx.NL;
+            const uint32_t nthr = nxW & ~(uint32_t)(nx.DS >> 1) & 0x7FFFFFFFu;
+            const uint32_t nmore = jtk_fill_down32(nxNL, nthr);
+            const uint32_t nund = jtk_fill_down32(nxW & ~nxNL & 0x80000000u, nthr) & ~nmore;
+            const uint64_t more = jtk_fill_down(cu.NL | (top & ((uint64_t)(nmore & 1u) << 63)), thr);
+            undecided = jtk_fill_down(top & ((uint64_t)(nund & 1u) << 63), thr) & ~more;
+            Wms |= cand & ~more & ~undecided;
+        }
+        slow = cand & undecided;
         if (cy.sw_unknown) {
             // the chain's origin is not visible: its bytes, and the char right after it, go the slow way
             const uint64_t after0 = (chain0 << 1) & wlead & ~cu.NL;
@@ -168,7 +235,7 @@ JTK_HD uint64_t jtk_split_block(const JtkBlk& cu, const JtkBlk& nx, JtkSplitCarr
         cy.sw_unknown = cy.sw_unknown && whole;
     }
 
-    const uint64_t ms = cu.DS | mso | Lms | Nms | Wms;
+    const uint64_t ms = (cu.DS | mso | Lms | Nms | Wms) & ~slow;
 
     // ---- carry for the next block
     if (cl) {

@@ -75,7 +75,7 @@ static JtkBlk make_blk(const uint8_t* text, int64_t n, const uint8_t* cb, int64_
 
 template <int KIND>
 static void sim_split_masks_t(const uint8_t* text, int64_t n, const uint8_t* cbv, int wave_blocks, uint8_t* ms_out,
-                              int64_t* n_slow) {
+                              int64_t* n_slow, int64_t* stats = nullptr) {
     Win w{text, n, cbv};
     const bool ci = KIND == JTK_PAT_CL100K;
     const int64_t nblk = (n + 1 + 63) / 64;
@@ -88,6 +88,16 @@ static void sim_split_masks_t(const uint8_t* text, int64_t n, const uint8_t* cbv
             uint64_t slow = 0, nl = 0;
             const JtkSplitCarry before = cy;
             uint64_t ms = jtk_split_block<KIND>(cu, nx, cy, slow, nl);
+            if (KIND == JTK_PAT_CL100K && nl && (cu.N & cu.CONT) == 0) {    // as the kernel does
+                uint64_t nslow;
+                ms |= jtk_split_n_block(cu, before.pN, before.ncnt, before.n_unknown, nslow);
+                slow |= nslow;
+                nl = 0;
+            }
+            if (stats) {
+                stats[0]++; stats[1] += __builtin_popcountll(slow); stats[2] += __builtin_popcountll(nl);
+                stats[3] += slow != 0; stats[4] += nl != 0;
+            }
             for (int j = 0; j < 64; j++) {
                 const int64_t p = b * 64 + j;
                 if (p > n) break;
@@ -100,6 +110,20 @@ static void sim_split_masks_t(const uint8_t* text, int64_t n, const uint8_t* cbv
             cu = nx;
         }
     }
+}
+
+// blocks, slow positions, digit-lane positions, blocks with any of either (what the kernel's per-position loops see)
+extern "C" int sim_split_stats(int kind, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs, int64_t* stats) {
+    JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};
+    std::vector<uint8_t> cb((size_t)n + 1), ms((size_t)n + 1);
+    Txt txt{text, n};
+    for (int64_t p = 0; p < n; p++) cb[p] = (uint8_t)jtk_class_byte(txt, u, p);
+    for (int64_t d = 0; d <= n_docs; d++) if (doc_off[d] < n) cb[doc_off[d]] |= JTK_CB_DS;
+    int64_t n_slow = 0;
+    for (int i = 0; i < 5; i++) stats[i] = 0;
+    if (kind == JTK_PAT_CL100K) sim_split_masks_t<JTK_PAT_CL100K>(text, n, cb.data(), 62, ms.data(), &n_slow, stats);
+    else sim_split_masks_t<JTK_PAT_R50K>(text, n, cb.data(), 62, ms.data(), &n_slow, stats);
+    return 0;
 }
 
 extern "C" int sim_split_masks(int kind, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs,
@@ -122,11 +146,20 @@ extern "C" int64_t sim_block_classify_check(int kind, const uint8_t* text, int64
     Txt txt{text, n};
     for (int64_t p = 0; p < n; p++) cb[p] = (uint8_t)jtk_class_byte(txt, u, p);
     const bool ci = kind == JTK_PAT_CL100K;
-    uint16_t codes[256];
-    for (int b = 0; b < 256; b++) codes[b] = (uint16_t)jtk_byte_code((uint32_t)b, ci);
+    JtkCode4 codes[256];
+    for (int b = 0; b < 256; b++)
+        codes[b] = jtk_code4(jtk_byte_code((uint32_t)b, ci) | (jtk_lead_all_letters(u, (uint32_t)b) ? (uint32_t)JTK_F_ULL : 0u));
     const int64_t nblk = (n + 63) / 64;
     int64_t bad = 0;
     uint32_t spill = JTK_CLS_O;
+    struct Words {                                   // the 4 bytes that start at byte j of block b (zero beyond the text)
+        const uint8_t* t; int64_t n, base;
+        uint32_t word(int j) const {
+            uint32_t v = 0;
+            for (int r = 0; r < 4; r++) { const int64_t p = base + j + r; if (p < n) v |= (uint32_t)t[p] << (8 * r); }
+            return v;
+        }
+    };
     for (int64_t b = 0; b < nblk; b++) {
         uint32_t d[16];
         for (int q = 0; q < 16; q++) {
@@ -136,10 +169,11 @@ extern "C" int64_t sim_block_classify_check(int kind, const uint8_t* text, int64
         }
         JtkBlk k;
         memset(&k, 0, sizeof(k));
-        uint64_t lead = 0;
-        jtk_block_masks_ascii(d, codes, k, lead);
+        uint64_t lead = 0, lt = 0, ull = 0;
+        jtk_block_masks_ascii(d, codes, k, lead, lt, ull);
         uint32_t my_spill;
-        jtk_block_fix_nonascii(txt, u, b * 64, lead, k, my_spill);
+        const Words wtxt{text, n, b * 64};
+        jtk_block_fix_nonascii(wtxt, u, lead, ull, k, my_spill);
         jtk_block_apply_spill(k, spill);
         spill = my_spill;
         JtkBlk ref = make_blk(text, n, cb.data(), b, ci);

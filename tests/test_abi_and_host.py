@@ -88,6 +88,9 @@ def sim():
     L.sim_tok8_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.sim_tok8_count.restype = C.c_int64
     L.sim_tok8_count.argtypes = [C.c_void_p]
+    L.sim_split_masks.argtypes = [C.c_int, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.sim_block_classify_check.restype = C.c_int64
+    L.sim_block_classify_check.argtypes = [C.c_int, C.c_char_p, C.c_int64]
     return L
 
 
@@ -119,6 +122,60 @@ def test_split_rules_match_oracle(sim, name, kind):
     for d in docs:
         exp += enc.split(d)
     assert _sim_pieces(sim, kind, docs) == exp
+
+
+@pytest.mark.parametrize("kind", [1, 0])
+def test_mask_algebra_matches_per_byte_rules(sim, kind):
+    """jtk_split_masks.h (the rules for 64 bytes at a time, with carries between blocks and the per-position fallbacks) vs
+    jtk_split_rules.h position by position, for waves of 62, 3 and 1 blocks; also bounds how often the fallback runs."""
+    from jtokkit_amd import corpus
+    rng = random.Random(17 + kind)
+    batches = []
+    for _ in range(300):
+        docs = [rc.random_text(rng, rng.choice((5, 30, 200))) for _ in range(rng.randint(1, 6))]
+        batches.append([d.encode("utf-8") for d in docs])
+    t, o = corpus.mixed(40, mean_bytes=2048, lo=256, hi=8192)
+    batches.append([t[o[i]:o[i + 1]].tobytes() for i in range(len(o) - 1)])
+    ws = " \t\n\r\u3000\u00a0"
+    for _ in range(200):                                   # whitespace / newline / digit runs across block edges
+        parts = []
+        for _ in range(rng.randint(2, 12)):
+            k = rng.random()
+            if k < 0.4: parts.append("".join(rng.choice(ws) for _ in range(rng.randint(1, 90))))
+            elif k < 0.6: parts.append("".join(rng.choice("0123456789\u0663\uff15") for _ in range(rng.randint(1, 150))))
+            else: parts.append(rng.choice(["x", ";", "word", "'s", "\u4e2d", ")", "a1"]))
+        batches.append(["".join(parts).encode("utf-8")])
+    total = slow_total = 0
+    for bs in batches:
+        text = b"".join(bs)
+        off = np.zeros(len(bs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(b) for b in bs])
+        ref = np.zeros(len(text) + 1, dtype=np.uint8)
+        sim.sim_split(kind, text, len(text), off.ctypes.data, len(bs), ref.ctypes.data)
+        for wave_blocks in (62, 3, 1):
+            ms = np.zeros(len(text) + 1, dtype=np.uint8)
+            n_slow = C.c_int64(0)
+            sim.sim_split_masks(kind, text, len(text), off.ctypes.data, len(bs), wave_blocks, ms.ctypes.data, C.byref(n_slow))
+            assert np.array_equal(ms, ref), (wave_blocks, bs)
+            if wave_blocks == 62:
+                total += len(text)
+                slow_total += n_slow.value
+    assert slow_total < 0.005 * total, (slow_total, total)
+
+
+@pytest.mark.parametrize("kind", [1, 0])
+def test_block_classification_matches_per_byte_rules(sim, kind):
+    """jtk_block_classify.h (one lane classifies 64 bytes: flag table + shift-or accumulation, 'all letters' lead bytes,
+    per-character decode of the rest) vs the per-byte class rule, on fuzz text, the mixed corpus and every code point."""
+    from jtokkit_amd import corpus
+    rng = random.Random(5 + kind)
+    texts = ["".join(rc.random_text(rng, 40) for _ in range(3000))]
+    texts.append(corpus.mixed(60, mean_bytes=2048, lo=256, hi=8192)[0].tobytes().decode("utf-8"))
+    every = "".join(chr(c) for c in range(1, 0x110000) if not 0xD800 <= c < 0xE000)
+    texts += [every, "a" + every, "ab" + every, "abc" + every]      # every alignment of every character in its block
+    for t in texts:
+        b = t.encode("utf-8")
+        assert sim.sim_block_classify_check(kind, b, len(b)) == 0
 
 
 @pytest.mark.parametrize("name,pairs", [("cl100k_base", 233378), ("r50k_base", 108299), ("p50k_base", 108599)])

@@ -13,8 +13,10 @@ pass() {
   echo "pass $name done"
 }
 BENCH_ARGS="$*"
+if [ -z "$PMC_SQ_ONLY" ]; then   # PMC_SQ_ONLY=1: instruction / wait counters only
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
+fi
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
 if [ -n "$PMC_CACHES" ]; then   # PMC_CACHES=1: also the cache counters (slow on large batches)
