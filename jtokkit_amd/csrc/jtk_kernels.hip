@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_validate_utf8(JtkWork w) {
 // split rules for the whole block as 64-bit mask algebra (jtk_split_masks.h).  Block-to-block carries
 // (digit-run phase, swallowed CR/LF chains, ...) are exchanged with __shfl_up and iterated to a fixed
 // point: one or two rounds unless a run spans several blocks.  Lanes 0 and 63 of a wave are halo
-// blocks, so a wave emits 62 mask words with one coalesced store; a workgroup covers 15,872 bytes.
+// blocks, so a wave emits 62 mask words with one coalesced store.
 // ---------------------------------------------------------------------------------------------------
 struct GlobalText {
     const uint8_t* t; int64_t n;
@@ -201,7 +201,8 @@ struct SlowWin {
 };
 
 constexpr int SPW = 62;                                // blocks a wave emits
-constexpr int SPLIT_BYTES = (SPLIT_THREADS / 64) * SPW * 64;   // bytes per workgroup
+constexpr int SPLIT_BYTES = (SPLIT_THREADS / 64) * SPW * 64;   // bytes per workgroup and pass
+constexpr int SPLIT_MAX_WGS = 512;
 
 __device__ __forceinline__ uint64_t hi_from_prev_lane(uint64_t v) {      // only the top bits are consumed
     return (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1) << 32;
@@ -220,7 +221,6 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
     __shared__ uint32_t s_uc_ready;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
     const int64_t n = w.n_bytes;
     if (tid < 256) {
         uint32_t code = jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
@@ -232,8 +232,12 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
     for (int i = tid; i < 2048; i += SPLIT_THREADS) s_pin[i] = t.pair_in_token[i];
     __syncthreads();
 
+    // The workgroups are persistent (the tables above are built once per CU slot): a wave takes every (waves in the
+    // grid)-th span of SPW blocks; there is no barrier between spans.
+    const int64_t spans = (n + 1 + SPW * 64 - 1) / (SPW * 64);
+    for (int64_t span = (int64_t)blockIdx.x * (SPLIT_THREADS / 64) + wv; span < spans; span += (int64_t)gridDim.x * (SPLIT_THREADS / 64)) {
     // ---- this lane's block
-    const int64_t p0 = B - 64 + (int64_t)(wv * SPW + lane) * 64;
+    const int64_t p0 = span * (SPW * 64) - 64 + (int64_t)lane * 64;
     uint32_t d[16];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -393,6 +397,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
         const int64_t wd = p0 >> 6;
         if (wd < w.n_words) w.piecemask[wd] = (ms | cut) & valid;
     }
+    }   // spans
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1917,7 +1922,8 @@ void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_validate_utf8, dim3((unsigned)((w.n_bytes + 255) / 256)), dim3(256), 0, s, w);
 }
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    const int64_t tiles = (w.n_bytes + 1 + SPLIT_BYTES - 1) / SPLIT_BYTES;
+    int64_t tiles = (w.n_bytes + 1 + SPLIT_BYTES - 1) / SPLIT_BYTES;
+    if (tiles > SPLIT_MAX_WGS) tiles = SPLIT_MAX_WGS;               // persistent workgroups (two fit a CU)
     if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
     else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
 }
