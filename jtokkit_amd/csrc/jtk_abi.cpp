@@ -175,9 +175,12 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); enc->longtok.release(); enc->longblob.release(); delete enc; };
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(JTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     ENC_TRY(hipSetDevice(device));
+    const size_t tok8_bytes = (enc->host.tok8.size() * sizeof(JtkTok8Slot) + 31) & ~(size_t)31;
     if (enc->uc1.ensure(sizeof(jtk_uc_stage1_init)) || enc->uc2.ensure(sizeof(jtk_uc_stage2_init)) ||
         enc->brank.ensure(256 * 4) || enc->pairs.ensure(enc->host.pair_buckets.size() * sizeof(JtkPairBucket)) ||
-        enc->tok8.ensure(enc->host.tok8.size() * sizeof(JtkTok8Slot)) || enc->tok16.ensure(enc->host.tok16.size() * sizeof(JtkTok16Slot)) ||
+        // the two whole-piece tables live in one allocation (tok8 slots, then tok16 slots): piece_resolve addresses both with
+        // one base and a 32-bit offset; + 32: a 9..16-byte probe of the last slot may read 16 bytes past a 16-byte slot
+        enc->tok8.ensure(tok8_bytes + enc->host.tok16.size() * sizeof(JtkTok16Slot) + 32) ||
         enc->bprank.ensure(65536 * 4) ||
         enc->bpbits.ensure(1024 * 8) || enc->bpcum.ensure(1024 * 2) || enc->bpranks.ensure(JTK_BP_MAX * 4) || enc->pairin.ensure(2048 * 4)) { cleanup(); return JTK_ERR_OUT_OF_MEMORY; }
     ENC_TRY(hipMemcpy(enc->uc1.p, jtk_uc_stage1_init, sizeof(jtk_uc_stage1_init), hipMemcpyHostToDevice));
@@ -185,7 +188,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     ENC_TRY(hipMemcpy(enc->brank.p, enc->host.byte_rank, 256 * 4, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->pairs.p, enc->host.pair_buckets.data(), enc->host.pair_buckets.size() * sizeof(JtkPairBucket), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->tok8.p, enc->host.tok8.data(), enc->host.tok8.size() * sizeof(JtkTok8Slot), hipMemcpyHostToDevice));
-    ENC_TRY(hipMemcpy(enc->tok16.p, enc->host.tok16.data(), enc->host.tok16.size() * sizeof(JtkTok16Slot), hipMemcpyHostToDevice));
+    ENC_TRY(hipMemcpy((uint8_t*)enc->tok8.p + tok8_bytes, enc->host.tok16.data(), enc->host.tok16.size() * sizeof(JtkTok16Slot), hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bprank.p, enc->host.bp_rank.data(), 65536 * 4, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bpbits.p, enc->host.bp_bits.data(), 1024 * 8, hipMemcpyHostToDevice));
     ENC_TRY(hipMemcpy(enc->bpcum.p, enc->host.bp_cum.data(), 1024 * 2, hipMemcpyHostToDevice));
@@ -228,7 +231,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     dt.pairs.bits = enc->host.pair_bits;
     dt.tok8.slots = (const JtkTok8Slot*)enc->tok8.p;
     dt.tok8.bits = enc->host.tok8_bits;
-    dt.tok16.slots = (const JtkTok16Slot*)enc->tok16.p;
+    dt.tok16.slots = (const JtkTok16Slot*)((const uint8_t*)enc->tok8.p + tok8_bytes);
     dt.tok16.n = enc->host.tok16_n;
     dt.bp_rank = (const uint32_t*)enc->bprank.p;
     dt.bp.bits = (const uint64_t*)enc->bpbits.p;

@@ -41,7 +41,8 @@
 #define JTK_BIN_CAP5 (JTK_TILE / 64)   //           65..128 bytes
 #define JTK_BIN_CAP6 (JTK_TILE / 128)  //           129..256 bytes
 // the head of a tile's slice of each bin's queue that pack stages in LDS: 32 + 16 + 16 results of the three classes of <= 16
-// bytes (staging slots 0..63), 8 of each longer bin (64..95); tiny pieces have a staging area of their own (JTK_PACK_TINY)
+// bytes (staging slots 0..63), 8 of each longer bin (64..95); tiny pieces have a staging area of their own (JTK_PACK_TINY).
+// (Three times as much -- enough for every tile of CJK text -- made pack 3 % faster on mixed text and 10 % slower on prose.)
 #define JTK_PACK_TINY 128
 #define JTK_PACK_SLOTS 96
 #define JTK_PACK_CAP(bin) ((bin) == 0 ? 32 : (bin) <= 2 ? 16 : 8)

@@ -474,19 +474,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             const uint32_t base = (uint32_t)__shfl((int)pre, wd);
             if ((m >> lane) & 1ull) s_plist[base + __popcll(m & lanemask_lt())] = (uint16_t)(wd * 64 + lane);
         }
+        if (tid == 0) {
+            // where the last piece ends: the sentinel (bit n) or the next tile's first piece; a piece of more than 64 KB only
+            // needs to look longer than every bin (its length is taken again, exactly, where it is queued)
+            const int64_t e = (n - B < T) ? (n - B) : (s_next_after - B);
+            s_plist[np] = (uint16_t)(e < 0xFFFF ? e : 0xFFFF);
+        }
     }
     __syncthreads();
+    if (np == 0) {                                                   // (all waves) a tile inside one long piece
+        if (tid == 0) { w.tile_np[tile] = 0; w.tile_tot[tile] = 0; }
+        if (tid < 16) w.q_meta[tile * 16 + tid] = 0;
+        return;
+    }
 
     // One lane per piece, two pieces per lane in flight.  A piece of <= 8 bytes looks itself up in the tok8 table, one
     // of 9..16 bytes in the tok16 table (the reference's whole-piece shortcut, :81-83).  The tables are primary-first
     // (jtk_common.h): ONE scattered fetch per piece (two adjacent words for a 9..16-byte piece) answers hit or miss unless
     // the slot is flagged "overflowed"; only those lanes read their secondary slot in a second round.
+    // The way to the answer is branch-free: every lane probes -- a lane beyond the list, or with a longer piece, looks
+    // up whatever 16 bytes it has and ignores the answer -- so the wave never splits before the rare cases.
     const int64_t next_after = s_next_after;
     const bool gaps = w.gapmask != nullptr;
-    const uint8_t* const t8 = reinterpret_cast<const uint8_t*>(t.tok8.slots);
-    const uint8_t* const t16 = reinterpret_cast<const uint8_t*>(t.tok16.slots);
+    const uint8_t* const tok = reinterpret_cast<const uint8_t*>(t.tok8.slots);   // the tok8 slots, then the tok16 slots: one allocation
+    const uint32_t rel16 = (uint32_t)(reinterpret_cast<const uint8_t*>(t.tok16.slots) - tok);
+    const uint32_t* const tw = reinterpret_cast<const uint32_t*>(s_tx);
     uint32_t* const plist = w.plist + B;
-    struct Probe { int s, len; uint32_t k0, k1, k2, k3, mix; uint4 ka; uint2 ma; };
+    struct Probe { uint32_t s, len, k0, k1, k2, k3, mix; uint4 ka; uint2 ma; };   // len 0: no piece
     auto piece_len = [&](int k, int s) -> int64_t {
         int64_t e;
         if (k + 1 < np) e = s_plist[k + 1];
@@ -494,55 +508,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                                                                       // (bit n) or at the next tile's first piece
         return e - s;
     };
+    auto slot_off = [&](uint32_t mix, bool small) -> uint32_t {       // byte offset of the slot in `tok`
+        const uint32_t h = jtk_reduce32(mix, small ? t.tok8.bits : t.tok16.n);
+        return (h << (small ? 4u : 5u)) + (small ? 0u : rel16);
+    };
     auto issue = [&](int k, Probe& pr) {
-        pr.s = -1; pr.len = 0;
-        if (k < np) {
-            const int s = s_plist[k];
-            const int64_t len64 = piece_len(k, s);
-            pr.s = s;
-            pr.len = len64 > 0x10000 ? 0x10000 : (int)len64;
-        }
-        pr.ka = make_uint4(0, 0, 0, 0);
+        const bool have = k < np;
+        const int kk = have ? k : np - 1;                             // np >= 1 here
+        const uint32_t s0 = s_plist[kk], e0 = s_plist[kk + 1];        // s_plist[np] = where the tile's last piece ends (clamped)
+        pr.s = have ? s0 : 0u;
+        pr.len = have ? e0 - s0 : 0u;
+        // up to 16 bytes of the piece, zero beyond its length
+        const uint32_t a = pr.s >> 2, sh = pr.s & 3u;
+        const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2], w3 = tw[a + 3], w4 = tw[a + 4];
+        const uint32_t len = pr.len < 16u ? pr.len : 16u;
+        const uint64_t run = ~0ull >> ((0u - 8u * len) & 63u);        // 8 len ones (len 8 and 16: all 64)
+        const bool big = len > 8u;
+        const uint64_t mlo = big ? ~0ull : run, mhi = big ? run : 0ull;
+        pr.k0 = __builtin_amdgcn_alignbyte(w1, w0, sh) & (uint32_t)mlo;
+        pr.k1 = __builtin_amdgcn_alignbyte(w2, w1, sh) & (uint32_t)(mlo >> 32);
+        pr.k2 = __builtin_amdgcn_alignbyte(w3, w2, sh) & (uint32_t)mhi;
+        pr.k3 = __builtin_amdgcn_alignbyte(w4, w3, sh) & (uint32_t)(mhi >> 32);
+        // one mix for both tables and both choices; only base, slot size and slot count depend on the length
+        pr.mix = jtk_tok16_mix(pr.k0, pr.k1, pr.k2, pr.k3, len);
+        const uint8_t* sa = tok + slot_off(pr.mix, !big);
+        pr.ka = *reinterpret_cast<const uint4*>(sa);                     // tok8: lo, hi, id, len; tok16: the 16 key bytes
         pr.ma = make_uint2(0, 0);
-        if (pr.s >= 0 && pr.len <= 16) {
-            // up to 16 bytes of the piece, zero beyond its length
-            const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tx);
-            const int a = pr.s >> 2;
-            const uint32_t sh = (uint32_t)(pr.s & 3);
-            const uint32_t w0 = tw[a], w1 = tw[a + 1], w2 = tw[a + 2], w3 = tw[a + 3], w4 = tw[a + 4];
-            uint32_t k[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
-                             __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)};
-            const uint32_t len = (uint32_t)pr.len, part = (1u << (8u * (len & 3u))) - 1u;   // mask of the last, partial word
-#pragma unroll
-            for (int q = 0; q < 4; q++) k[q] &= (len >= 4u * q + 4u) ? ~0u : (len > 4u * q ? part : 0u);
-            pr.k0 = k[0]; pr.k1 = k[1]; pr.k2 = k[2]; pr.k3 = k[3];
-            // one mix for both tables and both choices; only base, slot size and slot count depend on the length
-            pr.mix = jtk_tok16_mix(k[0], k[1], k[2], k[3], len);
-            const bool small = len <= 8u;
-            const uint8_t* sa = (small ? t8 : t16) + ((size_t)jtk_reduce32(pr.mix, small ? t.tok8.bits : t.tok16.n) << (small ? 4 : 5));
-            pr.ka = *reinterpret_cast<const uint4*>(sa);                 // tok8: lo, hi, id, len; tok16: the 16 key bytes
-            if (!small) pr.ma = *reinterpret_cast<const uint2*>(sa + 16);   // tok16: id, len
-        }
+        if (big) pr.ma = *reinterpret_cast<const uint2*>(sa + 16);       // tok16: id, len
     };
     // the answer of a slot: id, or JTK_RANK_NONE; `more`: a miss that the secondary slot has to confirm
     auto check = [&](const Probe& pr, uint32_t& id, bool& more) {
-        const uint32_t len = (uint32_t)pr.len;
-        const bool small = len <= 8u;
+        const bool small = pr.len <= 8u;
         const uint32_t slen = small ? pr.ka.w : pr.ma.y;
-        const bool hit = (slen & JTK_TOK_LEN_MASK) == len && pr.ka.x == pr.k0 && pr.ka.y == pr.k1 &&
-                         (small || (pr.ka.z == pr.k2 && pr.ka.w == pr.k3));
-        id = hit ? (small ? pr.ka.z : pr.ma.x) : JTK_RANK_NONE;
-        more = !hit && (slen & JTK_TOK_OVERFLOW) != 0u;
+        const uint32_t diff = (pr.ka.x ^ pr.k0) | (pr.ka.y ^ pr.k1) | ((slen & JTK_TOK_LEN_MASK) ^ pr.len) |
+                              (small ? 0u : ((pr.ka.z ^ pr.k2) | (pr.ka.w ^ pr.k3)));
+        id = diff == 0u ? (small ? pr.ka.z : pr.ma.x) : JTK_RANK_NONE;
+        more = diff != 0u && (slen & JTK_TOK_OVERFLOW) != 0u && pr.len - 1u < 16u;
     };
     auto issue2 = [&](Probe& pr) {                                       // secondary slot
-        const bool small = pr.len <= 8;
-        const uint8_t* sa = (small ? t8 : t16) + ((size_t)jtk_reduce32(jtk_pair_mix2(pr.mix), small ? t.tok8.bits : t.tok16.n) << (small ? 4 : 5));
+        const bool small = pr.len <= 8u;
+        const uint8_t* sa = tok + slot_off(jtk_pair_mix2(pr.mix), small);
         pr.ka = *reinterpret_cast<const uint4*>(sa);
         if (!small) pr.ma = *reinterpret_cast<const uint2*>(sa + 16);
     };
     auto resolve = [&](int k, const Probe& pr, uint32_t id) {
-        if (pr.s < 0) return;
-        const int s = pr.s, len = pr.len;
+        if (pr.len == 0u) return;
+        const int s = (int)pr.s, len = (int)pr.len;
         uint32_t entry = JTK_PL_HARD | JTK_PL_NOQUEUE | (uint32_t)s;
         int bin = -1;
         if (gaps && ((s_gap[s >> 6] >> (s & 63)) & 1ull)) {
@@ -594,13 +605,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int ka = c0 * 64 + lane, kb = (c0 + 4) * 64 + lane;
         Probe p0, p1;
         issue(ka, p0);
-        if (two) issue(kb, p1); else { p1.s = -1; p1.len = 0; }
+        if (two) issue(kb, p1); else { p1.s = 0; p1.len = 0; p1.ka = make_uint4(0, 0, 0, 0); p1.ma = make_uint2(0, 0); p1.k0 = p1.k1 = p1.k2 = p1.k3 = p1.mix = 0; }
         uint32_t id0, id1 = JTK_RANK_NONE;
         bool more0, more1 = false;
         check(p0, id0, more0);
         if (two) check(p1, id1, more1);
-        more0 = more0 && p0.s >= 0 && p0.len <= 16;
-        more1 = more1 && p1.s >= 0 && p1.len <= 16;
         if (__ballot(more0 || more1)) {
             if (more0) issue2(p0);
             if (more1) issue2(p1);
@@ -1649,7 +1658,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens + w.tile_off[tile]);
     uint32_t e[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { const int k = j * 64 + lane; e[j] = (k < np) ? plist[k] : 0u; }
+    for (int j = 0; j < 8; j++) e[j] = plist[j * 64 + lane];          // (not waiting for np: entries beyond it are zeroed below)
     if (lane < TW) {
         const int64_t dwd = (B >> 6) + lane;
         s_dm[lane] = (dwd < w.n_words) ? w.docmask[dwd] : 0ull;
@@ -1667,14 +1676,19 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     if (nq_hi) {                                                          // wave-uniform; rare in ordinary text
         const int bq = 3 + ((lane >> 3) & 3), il = lane & 7;
         const uint32_t qb = (uint32_t)__shfl((int)meta, bq), nq = (uint32_t)__shfl((int)meta, 8 + bq);
-        if (lane < 32 && (uint32_t)il < nq) s_qe[64 + lane] = (w.qd[bq] + shard * w.q_cap[bq] + qb)[il];
+        if (lane < 32 && (uint32_t)il < nq) s_qe[JTK_PACK_OFF(3) + lane] = (w.qd[bq] + shard * w.q_cap[bq] + qb)[il];
     }
     const uint32_t qb5 = (uint32_t)__shfl((int)meta, JTK_BIN_TINY), nq5 = (uint32_t)__shfl((int)meta, 8 + JTK_BIN_TINY);
     const uint2* const res5 = reinterpret_cast<const uint2*>(w.qt + shard * w.qt_cap + qb5);
     if (nq5) {                                                            // wave-uniform
-        if ((uint32_t)lane < nq5 && lane < PQT) s_qt[lane] = res5[lane];
-        if (PQT > 64 && (uint32_t)lane + 64u < nq5) s_qt[(64 + lane) % PQT] = res5[64 + lane];
+#pragma unroll
+        for (int r = 0; r < PQT / 64; r++) {
+            const uint32_t i = (uint32_t)(r * 64 + lane);
+            if (i < nq5) s_qt[i] = res5[i];
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 8; j++) e[j] = (j * 64 + lane < np) ? e[j] : 0u;
     wave_lds_fence();
     uint32_t run = 0;
     // a tiny piece's 8-byte result as a merge result word: the ids are where res_tok<0..2> looks, the count moves up
