@@ -201,8 +201,7 @@ struct SlowWin {
 };
 
 constexpr int SPW = 62;                                // blocks a wave emits
-constexpr int SPLIT_BYTES = (SPLIT_THREADS / 64) * SPW * 64;   // bytes per workgroup and pass
-constexpr int SPLIT_MAX_WGS = 512;
+constexpr int SPLIT_BYTES = (SPLIT_THREADS / 64) * SPW * 64;   // bytes per workgroup
 
 __device__ __forceinline__ uint64_t hi_from_prev_lane(uint64_t v) {      // only the top bits are consumed
     return (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1) << 32;
@@ -221,6 +220,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
     __shared__ uint32_t s_uc_ready;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t B = (int64_t)blockIdx.x * SPLIT_BYTES;
     const int64_t n = w.n_bytes;
     if (tid < 256) {
         uint32_t code = jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
@@ -232,12 +232,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
     for (int i = tid; i < 2048; i += SPLIT_THREADS) s_pin[i] = t.pair_in_token[i];
     __syncthreads();
 
-    // The workgroups are persistent (the tables above are built once per CU slot): a wave takes every (waves in the
-    // grid)-th span of SPW blocks; there is no barrier between spans.
-    const int64_t spans = (n + 1 + SPW * 64 - 1) / (SPW * 64);
-    for (int64_t span = (int64_t)blockIdx.x * (SPLIT_THREADS / 64) + wv; span < spans; span += (int64_t)gridDim.x * (SPLIT_THREADS / 64)) {
     // ---- this lane's block
-    const int64_t p0 = span * (SPW * 64) - 64 + (int64_t)lane * 64;
+    // (persistent workgroups -- a wave looping over spans -- were tried: the same speed, and 62 spilled registers)
+    const int64_t p0 = B - 64 + (int64_t)(wv * SPW + lane) * 64;
     uint32_t d[16];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -375,12 +372,26 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
     // is exact, so blocks of short ASCII pieces (ordinary text) skip the 64 bitmap lookups.
     uint64_t cut = 0;
     if ((lead | cu.CONT) != 0 || __popcll(ms) < 6) {
+        // The block's bytes are read again here (a cache hit) rather than kept in 16 registers through the rules above.
+        uint32_t dd[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t p = p0 + 16 * q;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p >= 0 && p + 16 <= n) v = *reinterpret_cast<const uint4*>(w.text + p);
+            else if (p >= 0 && p < n) {
+                uint32_t tmp[4] = {0, 0, 0, 0};
+                for (int r = 0; r < 16; r++) if (p + r < n) tmp[r >> 2] |= (uint32_t)w.text[p + r] << (8 * (r & 3));
+                v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+            }
+            dd[4 * q] = v.x; dd[4 * q + 1] = v.y; dd[4 * q + 2] = v.z; dd[4 * q + 3] = v.w;
+        }
         // pair (byte j-1, byte j) as an index: one byte permute; the bit accumulates from the top (alignbit), byte 0 ends at bit 0
         uint32_t acc[2] = {0u, 0u};
 #pragma unroll
         for (int j = 0; j < 64; j++) {
             const int q = j >> 2, r = j & 3;
-            const uint32_t hi = d[q], lo = (j >= 4) ? d[q - 1] : (prev_byte << 24);
+            const uint32_t hi = dd[q], lo = (j >= 4) ? dd[q - 1] : (prev_byte << 24);
             // index = prev << 8 | cur: byte 0 <- cur = hi byte r (selector 4 + r), byte 1 <- prev = hi byte r-1 or lo byte 3
             const uint32_t sel = 0x0C0C0000u | (uint32_t)(r ? (4 + r - 1) : 3) << 8 | (uint32_t)(4 + r);
             const uint32_t pi = __builtin_amdgcn_perm(hi, lo, sel);
@@ -397,7 +408,6 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
         const int64_t wd = p0 >> 6;
         if (wd < w.n_words) w.piecemask[wd] = (ms | cut) & valid;
     }
-    }   // spans
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1936,8 +1946,7 @@ void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_validate_utf8, dim3((unsigned)((w.n_bytes + 255) / 256)), dim3(256), 0, s, w);
 }
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    int64_t tiles = (w.n_bytes + 1 + SPLIT_BYTES - 1) / SPLIT_BYTES;
-    if (tiles > SPLIT_MAX_WGS) tiles = SPLIT_MAX_WGS;               // persistent workgroups (two fit a CU)
+    const int64_t tiles = (w.n_bytes + 1 + SPLIT_BYTES - 1) / SPLIT_BYTES;
     if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
     else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
 }
