@@ -415,6 +415,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
 // token (GptBytePairEncoding.java:81-83); every other piece is queued for bytePairMerge by length.
 // Writes the tile's piece list (plist): one word per piece, in text order.
 // ---------------------------------------------------------------------------------------------------
+#ifndef JTK_EXP
+#define JTK_EXP 0          // timing experiments (tools/r02_phases.sh): a kernel stops after one of its phases; results are wrong
+#endif
 constexpr int T = JTK_TILE;
 constexpr int TW = T / 64;                                          // mask words per tile
 static_assert(TW <= 64, "tile scans assume at most 64 mask words");
@@ -492,6 +495,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         }
     }
     __syncthreads();
+    if (JTK_EXP == 3) {   // (consistent, empty outputs: the kernels after this one have nothing to do)
+        if (tid == 0) { w.tile_np[tile] = 0; w.tile_tot[tile] = s_plist[np > 0 ? np - 1 : 0] == 0xFFFEu ? 1u : 0u; }
+        if (tid < 16) w.q_meta[tile * 16 + tid] = 0;
+        return;
+    }
     if (np == 0) {                                                   // (all waves) a tile inside one long piece
         if (tid == 0) { w.tile_np[tile] = 0; w.tile_tot[tile] = 0; }
         if (tid < 16) w.q_meta[tile * 16 + tid] = 0;
@@ -637,6 +645,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     // A tile with few merge pieces (ordinary text) leaves that to wave 0; the other waves are done and leave, so
     // their slots go to the next tile's workgroup while the atomic is in flight.
     const uint32_t n_queued = s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4] + s_qn[5] + s_qn[6] + s_qn[JTK_BIN_TINY];
+    if (JTK_EXP == 4) {
+        if (tid == 0) { w.tile_np[tile] = 0; w.tile_tot[tile] = n_queued == 0xFFFFFFu ? 1u : 0u; }
+        if (tid < 16) w.q_meta[tile * 16 + tid] = 0;
+        return;
+    }
     const bool all_waves = n_queued > 64u;                           // workgroup-uniform
     if (!all_waves && wv != 0) return;
     if (wv == 0) {
@@ -1522,11 +1535,14 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     __syncthreads();
     const LeanLds LL{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
     if (w5) tiny_bin<ML_THREADS>(w, LL, nt5);                    // (no parts in LDS: no barrier needed before the next phase)
+    if (JTK_EXP == 5) return;
     // (the three classes of <= 16 bytes share one LDS layout, [16 slots][1024 lanes], and a lane uses only its own column:
     // no barrier between them)
     if (w0) lean_bin<16, ML_THREADS, 0>(w, t, LL, n0);
+    if (JTK_EXP == 6) return;
     if (w1) lean_bin<16, ML_THREADS, 1>(w, t, LL, n1);
     if (w2) lean_bin<16, ML_THREADS, 2>(w, t, LL, n2);
+    if (JTK_EXP == 7) return;
     if (w3) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 3>(w, t, LL, n3); }
     if (w4) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 4>(w, t, LL, n4); }
     if (!rest) return;
@@ -1700,6 +1716,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
 #pragma unroll
     for (int j = 0; j < 8; j++) e[j] = (j * 64 + lane < np) ? e[j] : 0u;
     wave_lds_fence();
+    if (JTK_EXP == 1) { uint32_t x = 0; for (int j = 0; j < 8; j++) x ^= e[j]; if (x == 0x12345u) dst[lane] = s_qe[lane].x + (uint32_t)s_qt[lane].x; return; }
     uint32_t run = 0;
     // a tiny piece's 8-byte result as a merge result word: the ids are where res_tok<0..2> looks, the count moves up
     auto tiny_word = [](uint2 r) { return make_uint4(r.x, r.y & 0x3FFFFFFFu, 0u, (r.y >> 30) << 24); };
@@ -1780,6 +1797,7 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             else step(dst, e[j], k0 + j * 64 + lane);
         }
     }
+    if (JTK_EXP == 2) { if (s_out[lane] == 0x12345u) dst[lane] = run; return; }
     if (stage && store) {
         wave_lds_fence();
         for (uint32_t i = lane; i < total; i += WAVE) dst[i] = s_out[i];

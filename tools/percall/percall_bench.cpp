@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     const char* libp = argv[1]; const char* orap = argv[2]; const char* tikp = argv[3]; const char* corp = argv[4];
     const int T = atoi(argv[5]), K = atoi(argv[6]);
     const double secs = atof(argv[7]);
+    const int n_workers = argc > 8 ? atoi(argv[8]) : 2;                 // worker threads of the service (its default: 2)
     void* L = dlopen(libp, RTLD_NOW | RTLD_GLOBAL);
     if (!L) { fprintf(stderr, "%s\n", dlerror()); return 2; }
     auto enc_create = (int (*)(const char*, int, const uint8_t*, size_t, const char* const*, const int32_t*, int, int, jtk_encoding**))must(L, "jtk_encoding_create");
@@ -103,7 +104,7 @@ int main(int argc, char** argv) {
 
     // ---- service: blocking callers
     jtk_service* svc = nullptr;
-    if (svc_create(enc, 2, &svc) != 0) { fprintf(stderr, "service_create failed\n"); return 2; }
+    if (svc_create(enc, n_workers, &svc) != 0) { fprintf(stderr, "service_create failed\n"); return 2; }
     Res service = run([&](int t, std::atomic<bool>& stop, std::atomic<int64_t>& docs, std::atomic<int64_t>& bytes, std::atomic<int64_t>& toks) {
         std::vector<int32_t> out((size_t)max_len + 1);
         int64_t nd = 0, nb = 0, nt = 0;
@@ -164,12 +165,12 @@ int main(int argc, char** argv) {
             docs += nd; bytes += nb; toks += nt;
         });
     }
-    printf("{\"threads\": %d, \"in_flight_per_thread\": %d, \"seconds\": %.1f, \"docs\": %lld, \"mean_bytes\": %.1f, "
+    printf("{\"threads\": %d, \"service_workers\": %d, \"in_flight_per_thread\": %d, \"seconds\": %.1f, \"docs\": %lld, \"mean_bytes\": %.1f, "
            "\"direct\": {\"docs_per_s\": %.0f, \"MBps\": %.2f}, "
            "\"service_blocking\": {\"docs_per_s\": %.0f, \"MBps\": %.2f, \"docs_per_device_batch\": %.1f}, "
            "\"service_async\": {\"docs_per_s\": %.0f, \"MBps\": %.2f, \"docs_per_device_batch\": %.1f}, "
            "\"oracle_per_call\": {\"docs_per_s\": %.0f, \"MBps\": %.2f}}\n",
-           T, K, secs, (long long)n_docs, (double)off[n_docs] / (double)n_docs, direct.docs_s, direct.mb_s, service.docs_s, service.mb_s,
+           T, n_workers, K, secs, (long long)n_docs, (double)off[n_docs] / (double)n_docs, direct.docs_s, direct.mb_s, service.docs_s, service.mb_s,
            service.extra, async.docs_s, async.mb_s, async.extra, oracle.docs_s, oracle.mb_s);
     return 0;
 }
