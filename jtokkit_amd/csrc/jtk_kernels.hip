@@ -154,8 +154,8 @@ __global__ void __launch_bounds__(256) k_validate_utf8(JtkWork w) {
 
 // ---------------------------------------------------------------------------------------------------
 // pretok_split: ONE LANE PER 64-BYTE BLOCK.  A lane loads its block (4 x 16 B), classifies it through a
-// 256-entry byte-code table in LDS plus 8x8 bit transposes (jtk_block_classify.h), and evaluates the
-// split rules for the whole block as 64-bit mask algebra (jtk_split_masks.h).  Block-to-block carries
+// 256-entry table of 16 flags per byte value in LDS (shift-or accumulation, jtk_block_classify.h), and evaluates
+// the split rules for the whole block as 64-bit mask algebra (jtk_split_masks.h).  Block-to-block carries
 // (digit-run phase, swallowed CR/LF chains, ...) are exchanged with __shfl_up and iterated to a fixed
 // point: one or two rounds unless a run spans several blocks.  Lanes 0 and 63 of a wave are halo
 // blocks, so a wave emits 62 mask words with one coalesced store.
