@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Size sweep on one reused batch object (GPU box, not part of the suite): prefixes of one mixed-script text whose byte
-lengths straddle every internal boundary (64-byte blocks, 2 KiB tiles, the split kernel's 15,872-byte span), interleaved
+lengths straddle every internal boundary (64-byte blocks, 2 KiB tiles, the split kernel's 31,744-byte span and its halves), interleaved
 with longer batches, each compared with the oracle.  usage: python tools/soak_sizes.py"""
 import sys, random, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
@@ -17,7 +17,7 @@ def main():
         enc = jtokkit_amd.get_encoding(name); o = oracle_lib.get(name)
         b = enc.new_batch()
         targets = set()
-        for base in (64, 2048, 4096, 15872, 15872 * 2, 15872 * 3, 32768, 65536):
+        for base in (64, 2048, 4096, 15872, 15872 * 2, 15872 * 3, 31744 * 2, 32768, 65536):
             for d in range(-130, 131, 1 if base >= 2048 else 7):
                 if 0 < base + d <= len(raw): targets.add(base + d)
         for n in sorted(targets, key=lambda x: (x * 2654435761) % 1000003):       # shuffled: long and short alternate
