@@ -1740,10 +1740,16 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             // the common case, without divergent branches: exclusive scan of c (1 for most lanes, at most 7) by ballots of
             // the bits of c - 1, first tokens in one full store, the few further ones in sparse stores
             const uint32_t x = c ? c - 1u : 0u;
-            const uint64_t bv = __ballot(valid), lt = lanemask_lt();
+            const uint64_t bv = __ballot(valid);
             const uint64_t b0 = __ballot((x & 1u) != 0u), b1 = __ballot((x & 2u) != 0u), b2 = __ballot((x & 4u) != 0u);
-            pre = run + (uint32_t)__popcll(bv & lt) + (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
-            run += (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+            // set bits of a mask below this lane, added to acc: v_mbcnt_lo / _hi
+            auto below = [](uint64_t m, uint32_t acc) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, acc)); };
+            pre = below(b0, below(bv, run));
+            run += (uint32_t)__popcll(bv) + (uint32_t)__popcll(b0);
+            if (b1 | b2) {                                             // (wave-uniform) some piece became more than two tokens
+                pre += 2u * below(b1, 0u) + 4u * below(b2, 0u);
+                run += 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+            }
             if (valid) STORE(out[pre] = (hard ? qe.x : ej) & JTK_HT_ID_MASK);
             if (b0 | b1 | b2) {
                 if (c > 1u) STORE(out[pre + 1] = res_tok<1>(qe));
