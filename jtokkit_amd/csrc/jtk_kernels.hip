@@ -446,12 +446,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     const int64_t B = tile * T;
     const int64_t n = w.n_bytes;
 
-    for (int i = tid; i < (T + 16) / 4; i += 256) {
-        const int64_t p = B + (int64_t)i * 4;
-        uint32_t v = 0;
-        if (p + 4 <= n) v = *reinterpret_cast<const uint32_t*>(w.text + p);
-        else for (int j = 0; j < 4; j++) { if (p + j < n) v |= (uint32_t)w.text[p + j] << (8 * j); }
-        reinterpret_cast<uint32_t*>(s_tx)[i] = v;
+    if (tid < (T + 16) / 16) {                                       // the tile's text and the 16 bytes after it, 16 bytes per lane
+        const int64_t p = B + (int64_t)tid * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p + 16 <= n) v = *reinterpret_cast<const uint4*>(w.text + p);
+        else if (p < n) {
+            uint32_t tmp[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 16; j++) if (p + j < n) tmp[j >> 2] |= (uint32_t)w.text[p + j] << (8 * (j & 3));
+            v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+        }
+        reinterpret_cast<uint4*>(s_tx)[tid] = v;
     }
     if (tid < TW) {
         const int64_t wd = (B >> 6) + tid;
@@ -485,7 +489,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (int wd = wv; wd < TW; wd += 4) {
             const uint64_t m = s_pm[wd];
             const uint32_t base = (uint32_t)__shfl((int)pre, wd);
-            if ((m >> lane) & 1ull) s_plist[base + __popcll(m & lanemask_lt())] = (uint16_t)(wd * 64 + lane);
+            if ((m >> lane) & 1ull)
+                s_plist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(wd * 64 + lane);
         }
         if (tid == 0) {
             // where the last piece ends: the sentinel (bit n) or the next tile's first piece; a piece of more than 64 KB only
