@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ uint64_t s_pm[TW];
     __shared__ uint64_t s_gap[TW];
     __shared__ uint32_t s_q[Q_TOTAL];          // this tile's pieces for the merge kernels, by bin: offset | (len - 1) << 11 | index in this list << 19
-    __shared__ uint32_t s_qn[JTK_NBINS + 1], s_qb[JTK_NBINS + 1], s_nhard;
+    __shared__ uint32_t s_qn[JTK_NBINS + 1], s_qb[JTK_NBINS + 1], s_binc[JTK_NBINS + 1], s_nhard;
     __shared__ int64_t s_next_after;           // first piece start at or after B + T (global position)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -468,7 +468,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         s_pm[tid] = m;
         s_gap[tid] = (w.gapmask && wd < w.n_words) ? w.gapmask[wd] : 0ull;
     }
-    if (tid < JTK_NBINS + 1) s_qn[tid] = 0;
+    if (tid < JTK_NBINS + 1) {
+        s_qn[tid] = 0;
+        // per bin: where its pieces wait in s_q, how many of its results pack stages, and at which staging slot they start
+        s_binc[tid] = (uint32_t)q_off(tid) | (uint32_t)(tid == JTK_BIN_TINY ? JTK_PACK_TINY : JTK_PACK_CAP(tid)) << 12 |
+                      (uint32_t)(tid == JTK_BIN_TINY ? 0 : JTK_PACK_OFF(tid)) << 21;
+    }
     if (tid == 0) s_nhard = 0;
     if (tid == 64) {
         int64_t pos = -1;                                             // scan ahead for the next piece start
@@ -576,47 +581,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     };
     auto resolve = [&](int k, const Probe& pr, uint32_t id) {
         if (pr.len == 0u) return;
-        const int s = (int)pr.s, len = (int)pr.len;
-        uint32_t entry = JTK_PL_HARD | JTK_PL_NOQUEUE | (uint32_t)s;
-        int bin = -1;
-        if (gaps && ((s_gap[s >> 6] >> (s & 63)) & 1ull)) {
-            // text the caller's pattern did not match: no tokens (an htok header with count 0)
-            w.htok[B + s] = 0u;
-            atomicAdd(&s_nhard, 1u);
-        } else if (len <= 16) {
-            if (id != JTK_RANK_NONE) entry = id | ((uint32_t)s << JTK_PL_OFF_SHIFT);
-            else bin = (len <= 3) ? JTK_BIN_TINY : (len <= 8) ? 0 : (len <= 12) ? 1 : 2;   // (a 1-byte piece is always a table entry)
-        } else if (len <= 32) bin = 3;
-        else if (len <= 64) bin = 4;
-        else if (len <= 128) bin = 5;
-        else if (len <= JTK_BIN_MAXLEN) bin = 6;
-        else {
-            const int64_t len64 = piece_len(k, s);
-            if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
-            else if (len64 <= JTK_LONG_CAP) w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
-            else {
-                // giant piece (a run of one byte value, mostly): merged by a whole workgroup in the last phase of
-                // k_bpe_merge; its token count goes to giant_cnt, the htok header only says so
-                if (len64 <= JTK_GIANT_CAP) {
-                    const uint32_t gi = atomicAdd(w.n_giant, 1u);
-                    w.giant_list[gi] = JtkLongPiece{B + s, len64};
-                    w.giant_cnt[gi] = 0;
-                } else {
-                    const int64_t d = find_doc(w, B + s);
-                    if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
+        const uint32_t s = pr.s, len = pr.len;
+        const bool gap = gaps && ((s_gap[s >> 6] >> (s & 63u)) & 1ull);
+        uint32_t entry = id | (s << JTK_PL_OFF_SHIFT);                 // (a hit implies len <= 16)
+        if (gap || id == JTK_RANK_NONE) {
+            entry = JTK_PL_HARD | JTK_PL_NOQUEUE | s;
+            if (gap) {
+                // text the caller's pattern did not match: no tokens (an htok header with count 0)
+                w.htok[B + s] = 0u;
+                atomicAdd(&s_nhard, 1u);
+            } else if (len <= (uint32_t)JTK_BIN_MAXLEN) {
+                // bin by length: 2..3 tiny, 4..8, 9..12, 13..16 (three bits per length from a constant), then 17..32, ..64, ..128, ..256
+                // (a 1-byte piece is always a table entry)
+                constexpr uint64_t BIN16 = (7ull << 6) | (7ull << 9) | (1ull << 27) | (1ull << 30) | (1ull << 33) | (1ull << 36) |
+                                           (2ull << 39) | (2ull << 42) | (2ull << 45) | (2ull << 48);
+                const uint32_t bin = len <= 16u ? (uint32_t)(BIN16 >> (3u * len)) & 7u : 30u - (uint32_t)__builtin_clz(len - 1u);
+                const uint32_t bc = s_binc[bin];                           // q_off | staging cap << 12 | staging offset << 21
+                const uint32_t i = atomicAdd(&s_qn[bin], 1u);
+                s_q[(bc & 0xFFFu) + i] = s | ((len - 1u) << 11) | (i << 19);
+                // pack finds the result of one of the tile's first few pieces of a bin in its LDS staging area: say where
+                const bool st = i < ((bc >> 12) & 0x1FFu);
+                const uint32_t idx = st ? (bc >> 21) + i : i;
+                entry = JTK_PL_HARD | (st ? JTK_PL_STAGED : 0u) | (bin << JTK_PL_BIN_SHIFT) | (idx << JTK_PL_QI_SHIFT) | s;
+            } else {
+                const int64_t len64 = piece_len(k, (int)s);
+                if (len64 <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{B + s, len64};
+                else if (len64 <= JTK_LONG_CAP) w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
+                else {
+                    // giant piece (a run of one byte value, mostly): merged by a whole workgroup in the last phase of
+                    // k_bpe_merge; its token count goes to giant_cnt, the htok header only says so
+                    if (len64 <= JTK_GIANT_CAP) {
+                        const uint32_t gi = atomicAdd(w.n_giant, 1u);
+                        w.giant_list[gi] = JtkLongPiece{B + s, len64};
+                        w.giant_cnt[gi] = 0;
+                    } else {
+                        const int64_t d = find_doc(w, B + s);
+                        if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
+                    }
+                    w.htok[B + s] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;         // count: giant_cnt, or none at all
                 }
-                w.htok[B + s] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;         // count: giant_cnt, or none at all
+                atomicAdd(&s_nhard, 1u);
             }
-            atomicAdd(&s_nhard, 1u);
-        }
-        if (bin >= 0) {
-            const int qoff = q_off(bin);
-            const uint32_t i = atomicAdd(&s_qn[bin], 1u);
-            s_q[qoff + i] = (uint32_t)s | ((uint32_t)(len - 1) << 11) | (i << 19);
-            // pack finds the result of one of the tile's first few pieces of a bin in its LDS staging area: say where
-            const bool st = bin == JTK_BIN_TINY ? i < (uint32_t)JTK_PACK_TINY : i < (uint32_t)JTK_PACK_CAP(bin);
-            const uint32_t idx = (st && bin != JTK_BIN_TINY) ? (uint32_t)JTK_PACK_OFF(bin) + i : i;
-            entry = JTK_PL_HARD | (st ? JTK_PL_STAGED : 0u) | ((uint32_t)bin << JTK_PL_BIN_SHIFT) | (idx << JTK_PL_QI_SHIFT) | (uint32_t)s;
         }
         plist[k] = entry;
     };
