@@ -456,7 +456,7 @@ def per_call_record(args):
             f.write(np.int64(len(o) - 1).tobytes())
             f.write(o.tobytes())
             f.write(t.tobytes())
-        for threads, in_flight in ((16, 1), (64, 1), (4, 1024)):
+        for threads, in_flight in ((16, 1), (64, 1), (4, 1024), (8, 4096), (2, 8192)):
             p = subprocess.run([exe, os.path.join(ROOT, "jtokkit_amd", "libjtokkit_amd.so"),
                                 "-" if args.no_cpu_baseline else os.path.join(ROOT, "oracle", "libjtk_oracle.so"),
                                 os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken"), path, str(threads), str(in_flight), "1"],
