@@ -845,10 +845,9 @@ __device__ __forceinline__ uint32_t lean_piece16(const LeanLds& L, uint32_t* id,
 // such a piece makes no lookup that can hit beyond the 2-byte-token ranks of its byte pairs: merge the pair of lower rank,
 // the left one on a tie (:236), if either is a token; the pair that would follow is the whole piece, which is no entry.
 template <int THREADS>
-__device__ __forceinline__ void tiny_bin(const JtkWork& w, const LeanLds& L, uint32_t count) {
+__device__ __forceinline__ void tiny_bin(const JtkWork& w, const LeanLds& L, uint32_t count, uint32_t kq, uint32_t K) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int shard = blockIdx.x % JTK_Q_SHARDS;
-    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
     uint64_t* const q = w.qt + (int64_t)shard * w.qt_cap;
     for (uint32_t base = kq * THREADS; base < count; base += K * THREADS) {
         const uint32_t qi = base + (uint32_t)tid;
@@ -884,12 +883,11 @@ __device__ __forceinline__ void tiny_bin(const JtkWork& w, const LeanLds& L, uin
 }
 
 template <int SLOTS, int THREADS, int BIN>
-__device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables& t, const LeanLds& L, uint32_t count) {
+__device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables& t, const LeanLds& L, uint32_t count, uint32_t kq, uint32_t K) {
     typedef typename std::conditional<(SLOTS > 32), uint64_t, uint32_t>::type M;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid >= THREADS) return;
     const int shard = blockIdx.x % JTK_Q_SHARDS;
-    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
     uint32_t* const id = L.id + tid;
     uint32_t* const rk = L.rk + tid;
     const uint64_t* const qm = w.qm[BIN] + (int64_t)shard * w.q_cap[BIN];
@@ -1533,28 +1531,38 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     __syncthreads();
     // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
     const uint32_t n0 = s_count[0], n1 = s_count[1], n2 = s_count[2], n3 = s_count[3], n4 = s_count[4];
-    const bool w0 = kq * (uint32_t)ML_THREADS < n0, w1 = kq * (uint32_t)ML_THREADS < n1, w2 = kq * (uint32_t)ML_THREADS < n2,
-               w3 = kq * (uint32_t)(ML_THREADS / 2) < n3, w4 = kq * (uint32_t)(ML_THREADS / 4) < n4;
-    const bool rest = (s_count[5] | s_count[6] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
     const uint32_t nt5 = s_ntiny;
-    const bool w5 = kq * (uint32_t)ML_THREADS < nt5;
+    const bool rest = (s_count[5] | s_count[6] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
+    // Each phase is a chain of dependent lookups (as many as its longest piece has merges).  When every lean bin of the shard
+    // fits one workgroup pass -- small batches, where those chains ARE the kernel's time -- the shard's workgroups take one
+    // bin each, so the chains run side by side; otherwise every workgroup takes a slice of every bin.
+    const bool side_by_side = n0 <= (uint32_t)ML_THREADS && n1 <= (uint32_t)ML_THREADS && n2 <= (uint32_t)ML_THREADS &&
+                              nt5 <= (uint32_t)ML_THREADS && n3 <= (uint32_t)(ML_THREADS / 2) && n4 <= (uint32_t)(ML_THREADS / 4) &&
+                              gridDim.x / JTK_Q_SHARDS >= 4u;
+    const uint32_t K = side_by_side ? 1u : gridDim.x / JTK_Q_SHARDS, k = side_by_side ? 0u : kq;
+    bool w0, w1, w2, w3, w4, w5;
+    if (side_by_side) {
+        w0 = kq == 0u && n0; w1 = kq == 1u && n1; w2 = kq == 2u && n2;
+        w5 = kq == 3u && nt5; w3 = kq == 3u && n3; w4 = kq == 3u && n4;
+    } else {
+        w0 = kq * (uint32_t)ML_THREADS < n0; w1 = kq * (uint32_t)ML_THREADS < n1; w2 = kq * (uint32_t)ML_THREADS < n2;
+        w3 = kq * (uint32_t)(ML_THREADS / 2) < n3; w4 = kq * (uint32_t)(ML_THREADS / 4) < n4;
+        w5 = kq * (uint32_t)ML_THREADS < nt5;
+    }
     if (!(w0 || w1 || w2 || w3 || w4 || w5 || rest)) return;
     for (int i = tid; i < 1024; i += ML_THREADS) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
     if (tid < 256) s_brank[tid] = t.byte_rank[tid];
     __syncthreads();
     const LeanLds LL{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
-    if (w5) tiny_bin<ML_THREADS>(w, LL, nt5);                    // (no parts in LDS: no barrier needed before the next phase)
-    if (JTK_EXP == 5) return;
+    if (w5) tiny_bin<ML_THREADS>(w, LL, nt5, k, K);              // (no parts in LDS: no barrier needed before the next phase)
     // (the three classes of <= 16 bytes share one LDS layout, [16 slots][1024 lanes], and a lane uses only its own column:
     // no barrier between them)
-    if (w0) lean_bin<16, ML_THREADS, 0>(w, t, LL, n0);
-    if (JTK_EXP == 6) return;
-    if (w1) lean_bin<16, ML_THREADS, 1>(w, t, LL, n1);
-    if (w2) lean_bin<16, ML_THREADS, 2>(w, t, LL, n2);
-    if (JTK_EXP == 7) return;
-    if (w3) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 3>(w, t, LL, n3); }
-    if (w4) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 4>(w, t, LL, n4); }
+    if (w0) lean_bin<16, ML_THREADS, 0>(w, t, LL, n0, k, K);
+    if (w1) lean_bin<16, ML_THREADS, 1>(w, t, LL, n1, k, K);
+    if (w2) lean_bin<16, ML_THREADS, 2>(w, t, LL, n2, k, K);
+    if (w3) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 3>(w, t, LL, n3, k, K); }
+    if (w4) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 4>(w, t, LL, n4, k, K); }
     if (!rest) return;
     const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
     if (s_count[5]) { __syncthreads(); merge_bin<128, ML_WORDS / 128, 5>(w, t, L); }

@@ -4,13 +4,13 @@
 set -e
 if [ "$1" = build ]; then
   mkdir -p tools/exp
-  for n in 1 2 3 4 5 6 7; do make -s -C jtokkit_amd/csrc OUT=../../tools/exp/libjtk_exp$n.so EXTRA=-DJTK_EXP=$n; done
+  for n in 1 2 3 4; do make -s -C jtokkit_amd/csrc OUT=../../tools/exp/libjtk_exp$n.so EXTRA=-DJTK_EXP=$n; done
   exit 0
 fi
 root=$(pwd)
 mkdir -p gpurun_out/phases
 cd /tmp && export TMPDIR=/tmp
-for n in 0 1 2 3 4 5 6 7; do
+for n in 0 1 2 3 4; do
   if [ $n = 0 ]; then unset JTOKKIT_AMD_LIB; else export JTOKKIT_AMD_LIB=$root/tools/exp/libjtk_exp$n.so; fi
   for wl in "cfg2" "cfg3 --docs 250000"; do
     tag=$(echo $wl | cut -d' ' -f1)
