@@ -1,6 +1,8 @@
 #!/bin/bash
 # Where a kernel's time goes: libraries built with -DJTK_EXP=n stop a kernel after one of its phases (wrong results, right
 # timing).  Build here (hipcc), run on the GPU box:   bash tools/r02_phases.sh build | run
+# 1, 2: pack (loads only / no copy-out); 3, 4: piece_resolve (up to the piece list / up to the queue claim).  The merge's
+# phase numbers in DESIGN.md 5.3 were taken with hooks 5-7 of commit 8ec8051 (tiny only / + bin 0 / + bins 1, 2).
 set -e
 if [ "$1" = build ]; then
   mkdir -p tools/exp
