@@ -79,6 +79,7 @@ struct ChunkSet {
 
 constexpr int MAX_SETS = 4;
 constexpr int64_t SMALL_JOB_BYTES = 1 << 20;
+constexpr int64_t TINY_JOB_BYTES = 128 << 10;     // host jobs this small are staged so that offsets and text go down in one copy
 
 struct jtk_batch {
     const jtk_encoding* enc = nullptr;
@@ -95,8 +96,11 @@ struct jtk_batch {
     // the whole batch
     DevBuf in_text, in_off;          // device copy of host input (host-buffer entry point)
     DevBuf in_pieces;                // caller-supplied pieces (jtk_batch_encode_pieces): begin[n] | end[n]
-    DevBuf status, job;              // per document | JtkResult + running token totals per chunk
-    DevBuf tokens, tok_off;
+    // One allocation holds everything a job hands back: JtkResult + running token totals per chunk | status per document |
+    // token offsets | token ids.  A small job's whole answer is then ONE copy to the host, and its header one memset.
+    DevBuf out;
+    struct View { void* p = nullptr; };
+    View job, status, tok_off, tokens;   // where those parts are in `out` for the last job
     DevBuf plan;                     // chunk plan of a device-resident batch
     int64_t* host_plan = nullptr;    // pinned
     size_t host_plan_cap = 0;
@@ -105,6 +109,10 @@ struct jtk_batch {
     int32_t* h_tokens = nullptr; size_t h_tokens_cap = 0;
     int64_t* h_tok_off = nullptr; size_t h_tok_off_cap = 0;
     int32_t* h_status = nullptr; size_t h_status_cap = 0;
+    uint8_t* h_small = nullptr; size_t h_small_cap = 0;   // a small job's whole `out` block (pinned)
+    uint8_t* h_in = nullptr; size_t h_in_cap = 0;         // a tiny host job's offsets and text, side by side (pinned)
+    // where the host copy of the last job's result is: the buffers above, or inside h_small
+    const int32_t* r_tokens = nullptr; const int64_t* r_tok_off = nullptr; int32_t* r_status = nullptr;
     bool have_host_result = false;
     // batch decode (jtk_batch_decode*)
     DevBuf dec_in_ids, dec_in_off, dec_zero, dec_tile, dec_pre, dec_out, dec_byte_off;
@@ -113,7 +121,8 @@ struct jtk_batch {
     JtkDecodeWork dwork{};
     bool have_decode = false;
     int64_t dec_total = 0;
-    JtkResult* host_result = nullptr;   // pinned
+    JtkResult* host_result = nullptr;   // pinned: host_result_own, or the head of h_small after a small job
+    JtkResult* host_result_own = nullptr;
     // the last job
     const uint8_t* job_text = nullptr;
     const int64_t* job_doc_off = nullptr;
@@ -277,7 +286,8 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
     if (const char* e = getenv("JTK_HOST_CHUNK_BYTES")) { const long long v = atoll(e); if (v >= (1 << 16)) b->host_chunk_bytes = v; }
     if (const char* e = getenv("JTK_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= MAX_SETS) b->n_sets = v; }
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result, sizeof(JtkResult), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result_own, sizeof(JtkResult), hipHostMallocDefault);
+    b->host_result = b->host_result_own;
     // (the streams and events of the chunk pipeline are created by the first job that forks: a batch that only ever sees
     // small single-chunk jobs -- one per caller thread in the per-call shape -- owns one stream, not six)
     if (e != hipSuccess) {
@@ -301,7 +311,7 @@ void jtk_batch_destroy(jtk_batch* b) {
         if (cs.ev_done) (void)hipEventDestroy(cs.ev_done);
         if (cs.stream) (void)hipStreamDestroy(cs.stream);
     }
-    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->in_pieces, &b->status, &b->job, &b->tokens, &b->tok_off, &b->plan, &b->dec_in_ids, &b->dec_in_off,
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->in_pieces, &b->out, &b->plan, &b->dec_in_ids, &b->dec_in_off,
                       &b->dec_zero, &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag};
     for (DevBuf* d : bufs) d->release();
     for (hipEvent_t ev : b->prof_ev) (void)hipEventDestroy(ev);
@@ -309,7 +319,9 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (b->ev_copy) (void)hipEventDestroy(b->ev_copy);
     if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
     if (b->h_info) (void)hipHostFree(b->h_info);
-    if (b->host_result) (void)hipHostFree(b->host_result);
+    if (b->host_result_own) (void)hipHostFree(b->host_result_own);
+    if (b->h_small) (void)hipHostFree(b->h_small);
+    if (b->h_in) (void)hipHostFree(b->h_in);
     if (b->host_plan) (void)hipHostFree(b->host_plan);
     if (b->h_tokens) (void)hipHostFree(b->h_tokens);
     if (b->h_tok_off) (void)hipHostFree(b->h_tok_off);
@@ -452,23 +464,27 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
     int rc;
     // batch-wide buffers
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
-    const size_t job_bytes = 64 + ((size_t)n_chunks + 2) * 8;
-    if ((rc = b->status.ensure(status_bytes)) || (rc = b->job.ensure(job_bytes)) ||
-        (rc = b->tokens.ensure(((size_t)n_bytes + 64) * 4)) || (rc = b->tok_off.ensure(((size_t)n_docs + 1) * 8)))
-        return rc;
+    const size_t job_bytes = align_up(64 + ((size_t)n_chunks + 2) * 8, 16);
+    const size_t off_status = job_bytes, off_tok_off = off_status + status_bytes;
+    const size_t off_tokens = align_up(off_tok_off + ((size_t)n_docs + 1) * 8, 256);
+    if ((rc = b->out.ensure(off_tokens + ((size_t)n_bytes + 64) * 4))) return rc;
+    b->job.p = b->out.p;
+    b->status.p = (uint8_t*)b->out.p + off_status;
+    b->tok_off.p = (uint8_t*)b->out.p + off_tok_off;
+    b->tokens.p = (uint8_t*)b->out.p + off_tokens;
     JtkResult* d_result = (JtkResult*)b->job.p;
     int64_t* d_totals = (int64_t*)((uint8_t*)b->job.p + 64);       // [c]: tokens of the chunks before c
-    HIP_TRY(hipMemsetAsync(b->status.p, 0, status_bytes, s));
-    HIP_TRY(hipMemsetAsync(b->job.p, 0, job_bytes, s));
-    if (to_host) {
+    HIP_TRY(hipMemsetAsync(b->out.p, 0, off_tok_off, s));          // JtkResult, totals and status
+    // a small single-chunk job (the per-call service's batches) copies its whole output block -- header, status, offsets and
+    // the worst-case token range (one token per byte) -- right behind the kernels in ONE copy, instead of waiting for the
+    // token count first: one host synchronisation and three copies less per batch
+    const bool small_to_host = to_host && n_chunks == 1 && n_bytes <= SMALL_JOB_BYTES;
+    if (to_host && !small_to_host) {
         if ((rc = ensure_pinned((void**)&b->h_tok_off, &b->h_tok_off_cap, ((size_t)n_docs + 1) * 8, 0)) ||
             (rc = ensure_pinned((void**)&b->h_status, &b->h_status_cap, (size_t)(n_docs > 0 ? n_docs : 1) * 4, 0)) ||
             (rc = ensure_pinned((void**)&b->h_tokens, &b->h_tokens_cap, (size_t)n_bytes * (n_bytes <= SMALL_JOB_BYTES ? 4 : 2) + 4096, 0)))     // grown as the chunks report
             return rc;
     }
-    // a small single-chunk job (the per-call service's batches) copies the worst-case token range (one token per byte) right
-    // behind the kernels instead of waiting for the count first: one host synchronisation less per batch
-    const bool small_to_host = to_host && n_chunks == 1 && n_bytes <= SMALL_JOB_BYTES;
     const bool prof = b->profiling;
     if (prof) {
         const size_t need = (size_t)n_chunks * N_STAGES * 2;
@@ -587,8 +603,12 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         jtk_launch_doc_offsets(w, cst);
         end();
         HIP_TRY(hipGetLastError());
-        if (small_to_host && n_bytes > 0 && !(flags & JTK_ENCODE_COUNT_ONLY))
-            HIP_TRY(hipMemcpyAsync(b->h_tokens, b->tokens.p, (size_t)n_bytes * 4, hipMemcpyDeviceToHost, cst));
+        if (small_to_host) {
+            // the whole answer in one copy: header, status, offsets and the worst-case token range (one token per byte)
+            const size_t total = (flags & JTK_ENCODE_COUNT_ONLY) ? off_tokens : off_tokens + (size_t)n_bytes * 4;
+            if ((rc = ensure_pinned((void**)&b->h_small, &b->h_small_cap, total + 4096, 0))) return rc;
+            HIP_TRY(hipMemcpyAsync(b->h_small, b->out.p, total, hipMemcpyDeviceToHost, cst));
+        }
         if (fork) HIP_TRY(hipEventRecord(cs.ev_done, cst));
         if (to_host && !small_to_host && c > 0) { if ((rc = send_chunk_to_host(c - 1)) != JTK_OK) return rc; }
     }
@@ -601,11 +621,20 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
             HIP_TRY(hipStreamWaitEvent(s, b->ev_copy, 0));
         }
     }
-    if (to_host) {
-        HIP_TRY(hipMemcpyAsync(b->h_tok_off, b->tok_off.p, ((size_t)n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
-        if (n_docs > 0) HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost, s));
+    if (small_to_host) {
+        b->host_result = (JtkResult*)b->h_small;
+        b->r_status = (int32_t*)(b->h_small + off_status);
+        b->r_tok_off = (const int64_t*)(b->h_small + off_tok_off);
+        b->r_tokens = (const int32_t*)(b->h_small + off_tokens);
+    } else {
+        if (to_host) {
+            HIP_TRY(hipMemcpyAsync(b->h_tok_off, b->tok_off.p, ((size_t)n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+            if (n_docs > 0) HIP_TRY(hipMemcpyAsync(b->h_status, b->status.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost, s));
+        }
+        b->host_result = b->host_result_own;
+        HIP_TRY(hipMemcpyAsync(b->host_result, d_result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
+        b->r_status = b->h_status; b->r_tok_off = b->h_tok_off; b->r_tokens = b->h_tokens;
     }
-    HIP_TRY(hipMemcpyAsync(b->host_result, d_result, sizeof(JtkResult), hipMemcpyDeviceToHost, s));
     b->job_text = d_text;
     b->job_doc_off = d_doc_off;
     b->job_docs = n_docs;
@@ -695,10 +724,22 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
     b->chunk_off.push_back(n_bytes);
     HIP_TRY(hipSetDevice(b->enc->device));
     int rc;
-    if ((rc = b->in_text.ensure((size_t)n_bytes + 64)) || (rc = b->in_off.ensure(((size_t)n_docs + 1) * 8))) return rc;
-    HIP_TRY(hipMemcpyAsync(b->in_off.p, doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
-    rc = run_job(b, (const uint8_t*)b->in_text.p, utf8, (const int64_t*)b->in_off.p, n_docs, n_bytes, flags & ~(uint32_t)JTK_ENCODE_TO_HOST,
-                 b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
+    if (b->chunk_doc.size() == 2 && n_bytes <= TINY_JOB_BYTES) {
+        // a per-call device batch: offsets and text go down in ONE copy (staged side by side in pinned memory; copying a few KB on
+        // the host costs less than a second DMA)
+        const size_t off_text = align_up(((size_t)n_docs + 1) * 8, 256), total = off_text + (size_t)n_bytes;
+        if ((rc = ensure_pinned((void**)&b->h_in, &b->h_in_cap, total + 64, 0)) || (rc = b->in_text.ensure(total + 64))) return rc;
+        memcpy(b->h_in, doc_off, ((size_t)n_docs + 1) * 8);
+        if (n_bytes > 0) memcpy(b->h_in + off_text, utf8, (size_t)n_bytes);
+        HIP_TRY(hipMemcpyAsync(b->in_text.p, b->h_in, total, hipMemcpyHostToDevice, b->stream));
+        rc = run_job(b, (const uint8_t*)b->in_text.p + off_text, nullptr, (const int64_t*)b->in_text.p, n_docs, n_bytes,
+                     flags & ~(uint32_t)JTK_ENCODE_TO_HOST, b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
+    } else {
+        if ((rc = b->in_text.ensure((size_t)n_bytes + 64)) || (rc = b->in_off.ensure(((size_t)n_docs + 1) * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(b->in_off.p, doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
+        rc = run_job(b, (const uint8_t*)b->in_text.p, utf8, (const int64_t*)b->in_off.p, n_docs, n_bytes, flags & ~(uint32_t)JTK_ENCODE_TO_HOST,
+                     b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
+    }
     if (rc != JTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->synced = true;
@@ -781,7 +822,7 @@ int jtk_batch_encode_pieces(jtk_batch* b, const uint8_t* utf8, const int64_t* do
         const int32_t st = JTK_ERR_UNSUPPORTED_SPECIAL;
         for (int64_t d : special_docs) {
             HIP_TRY(hipMemcpy((int32_t*)b->status.p + d, &st, 4, hipMemcpyHostToDevice));
-            if (b->have_host_result) b->h_status[d] = st;
+            if (b->have_host_result) b->r_status[d] = st;
         }
         if (b->host_result->worst_status > st) b->host_result->worst_status = st;
     }
@@ -811,7 +852,7 @@ int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* 
         if (count_only) return fail(JTK_ERR_INVALID_ARGUMENT, "the last encode was count-only: there are no token ids");
         if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
         if (nt > 0) {
-            if (b->have_host_result) memcpy(tokens, b->h_tokens, (size_t)nt * 4);
+            if (b->have_host_result) memcpy(tokens, b->r_tokens, (size_t)nt * 4);
             else HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
         }
     }
@@ -826,9 +867,9 @@ int jtk_batch_host_result(jtk_batch* b, const int32_t** tokens, const int64_t** 
         return fail(JTK_ERR_INVALID_ARGUMENT, "the last encode on this batch did not run with JTK_ENCODE_TO_HOST");
     HIP_TRY(hipSetDevice(b->enc->device));
     if (!b->synced) { HIP_TRY(hipStreamSynchronize(b->last_stream)); b->synced = true; }
-    if (tokens) *tokens = (b->job_flags & JTK_ENCODE_COUNT_ONLY) ? nullptr : b->h_tokens;
-    if (tok_off) *tok_off = b->h_tok_off;
-    if (status) *status = b->h_status;
+    if (tokens) *tokens = (b->job_flags & JTK_ENCODE_COUNT_ONLY) ? nullptr : b->r_tokens;
+    if (tok_off) *tok_off = b->r_tok_off;
+    if (status) *status = b->r_status;
     return JTK_OK;
 }
 
