@@ -551,6 +551,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         w.job_tokens_next = d_totals + c + 1;
         w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
         w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
+        w.inline_scan = (!fork && n_chunks == 1 && w.n_tiles >= 1 && w.n_tiles <= 1024) ? 1u : 0u;
 
         if (fork && !cs.used) { HIP_TRY(hipStreamWaitEvent(cst, b->ev_fork, 0)); cs.used = true; }
         if (h_text && b1 > b0) {
@@ -593,7 +594,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         end();
         begin();
         if (fork && c > 0) HIP_TRY(hipStreamWaitEvent(cst, b->set[(c - 1) % n_sets].ev_scan, 0));
-        jtk_launch_tile_scan(w, cst);
+        if (!w.inline_scan) jtk_launch_tile_scan(w, cst);
         if (fork) HIP_TRY(hipEventRecord(cs.ev_scan, cst));
         end();
         begin();

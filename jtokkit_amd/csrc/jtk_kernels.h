@@ -120,6 +120,7 @@ struct JtkWork {
     int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
     int64_t n_tiles;
     uint32_t count_only;    // countTokens(): pack computes the offsets but writes no token ids
+    uint32_t inline_scan;   // small single-chunk job: pack adds up the tiles before its own itself and k_tile_scan is not launched
     uint32_t check_special; // encode(): flag documents that contain a special-token literal (done inside pretok_split)
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)

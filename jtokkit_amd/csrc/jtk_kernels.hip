@@ -1699,7 +1699,28 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
     const bool stage = total <= (uint32_t)PACK_STAGE;
     const bool store = w.count_only == 0;     // countTokens(): offsets only, no token ids
     const uint32_t* plist = w.plist + B;
-    uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens + w.tile_off[tile]);
+    int64_t tile_base;
+    if (w.inline_scan) {
+        // a small job (at most 1024 tiles): the tokens before this tile, added up here -- one launch less
+        uint32_t part = 0;
+        for (int64_t i = lane; i < tile; i += 64) part += w.tile_tot[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d);
+        const int64_t job_before = *w.job_tokens;
+        tile_base = job_before + (int64_t)part;
+        if (lane == 0) {
+            w.tile_off[tile] = tile_base;
+            if (tile == w.n_tiles - 1) {
+                const int64_t end = tile_base + (int64_t)total;
+                w.tile_off[w.n_tiles] = end;
+                w.set_info[0] = job_before;
+                w.set_info[1] = end;
+                w.result->n_tokens = end;
+                *w.job_tokens_next = end;
+            }
+        }
+    } else tile_base = w.tile_off[tile];
+    uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens + tile_base);
     uint32_t e[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) e[j] = plist[j * 64 + lane];          // (not waiting for np: entries beyond it are zeroed below)
