@@ -455,14 +455,15 @@ def test_many_tiny_and_empty_documents(jt):
 
 def test_batch_reuse_shorter_batch_after_longer(jt):
     """One batch object, a long batch and then shorter ones whose length lands just below a multiple of the split
-    kernel's 15,872-byte span (the mask words after the end are then not rewritten): nothing of the earlier batch may
+    kernel's span (31,744 bytes per workgroup, 3,968 per wave; 15,872 per workgroup in round 1: the mask words after the end are then not rewritten): nothing of the earlier batch may
     leak into the later results.  Found by the randomized soak run (tools/soak_check.py)."""
     enc = jt.get_encoding("r50k_base")
     o = oracle_lib.get("r50k_base")
     b = enc.new_batch()
     long_text = np.frombuffer(("a b\r\nc 1 " * 20000).encode(), dtype=np.uint8)
     b.encode_host(long_text, np.array([0, len(long_text)], dtype=np.int64), ordinary=True)
-    for n in (15872 * 2 - 2, 15872 * 2 - 1, 15872 * 3 - 64, 15872 - 130, 15872 * 4 - 127, 2047, 2048, 4095):
+    for n in (15872 * 2 - 2, 15872 * 2 - 1, 15872 * 3 - 64, 15872 - 130, 15872 * 4 - 127, 31744 * 2 - 1, 31744 * 3 - 64, 3968 * 5 - 3,
+              2047, 2048, 4095):
         body = ("日" * (n // 3))[: n // 3]
         doc = (body.encode() + b"\n" * n)[:n]
         text = np.frombuffer(doc, dtype=np.uint8)
