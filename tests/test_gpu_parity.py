@@ -693,6 +693,56 @@ def test_comm_stitch_one_rank_rehearsal(jt):
     b.close()
 
 
+def test_service_submit_wait_pipelines(jt):
+    """jtk_service_submit / jtk_service_wait from several producer threads, each keeping a few hundred documents in flight
+    (the service's queue is sharded by producer thread; a device batch then holds documents of all of them): every ticket
+    comes back with exactly its own document's tokens."""
+    import ctypes as C
+    import threading
+    from jtokkit_amd import _native as N, corpus
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = corpus.sentences(2400, seed=61)
+    t2, o2 = corpus.mixed(400, mean_bytes=900, lo=64, hi=6000, seed=62)
+    docs = [text[doc_off[d]:doc_off[d + 1]].tobytes() for d in range(len(doc_off) - 1)]
+    docs += [t2[o2[d]:o2[d + 1]].tobytes() for d in range(len(o2) - 1)] + [b"", b"x"]
+    want = [o.encode_ordinary(d) for d in docs]
+    svc = enc._service()
+    lib = N.lib()
+    errors = []
+    n_threads, window = 6, 300
+
+    def producer(t):
+        try:
+            mine = list(range(t, len(docs), n_threads))
+            outs = [np.empty(len(docs[i]) + 1, dtype=np.int32) for i in mine]
+            tickets = [C.c_void_p() for _ in mine]
+
+            def finish(k):
+                nt, tr = C.c_int64(0), C.c_int(0)
+                rc = lib.jtk_service_wait(svc, tickets[k], C.byref(nt), C.byref(tr))
+                assert rc == 0, (rc, mine[k])
+                assert outs[k][:nt.value].tolist() == want[mine[k]], mine[k]
+
+            for k, i in enumerate(mine):
+                rc = lib.jtk_service_submit(svc, docs[i], len(docs[i]), N.JTK_ENCODE_ORDINARY, -1, outs[k].ctypes.data, len(outs[k]),
+                                            C.byref(tickets[k]))
+                assert rc == 0, (rc, i)
+                if k >= window:
+                    finish(k - window)
+            for k in range(max(0, len(mine) - window), len(mine)):
+                finish(k)
+        except BaseException as ex:          # noqa: BLE001 -- reported to the main thread
+            errors.append((t, repr(ex)))
+
+    th = [threading.Thread(target=producer, args=(t,)) for t in range(n_threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:3]
+
+
 def test_per_call_methods_from_many_threads(jt):
     """The reference's calling shape: Encoding.encode(String) per document from a pool of threads
     (benchmark/.../AbstractMultiThreadedBenchmark.java:35-45).  The per-call methods are thread-safe and coalesced into device
