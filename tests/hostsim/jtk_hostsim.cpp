@@ -189,6 +189,11 @@ extern "C" int64_t sim_block_classify_check(int kind, const uint8_t* text, int64
     return bad;
 }
 
+extern "C" int sim_lead_all_letters(int b) {
+    JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};
+    return jtk_lead_all_letters(u, (uint32_t)b) ? 1 : 0;
+}
+
 extern "C" {
 uint32_t sim_class_byte(const uint8_t* text, int64_t n, int64_t p) {
     JtkUcTables u{jtk_uc_stage1_init, jtk_uc_stage2_init};

@@ -163,6 +163,33 @@ def test_mask_algebra_matches_per_byte_rules(sim, kind):
     assert slow_total < 0.005 * total, (slow_total, total)
 
 
+def test_lead_bytes_whose_characters_are_all_letters(sim):
+    """jtk_lead_all_letters (the split kernel skips the decode of such characters): checked against Python's Unicode data
+    for every lead byte -- CJK ideographs U+5000-8FFF, Hangul U+B000-CFFF and basic Cyrillic qualify; U+4000-4FFF (hexagram
+    symbols at U+4DC0) and U+9000-9FFF (unassigned tail) do not."""
+    import unicodedata
+    if not unicodedata.unidata_version.startswith("13."):
+        pytest.skip("class tables are Unicode 13.0")
+
+    def rng(b):
+        if 0xC2 <= b <= 0xDF: return ((b & 0x1F) << 6, ((b & 0x1F) << 6) + 63)
+        if b == 0xE0: return (0x800, 0xFFF)
+        if b == 0xED: return (0xD000, 0xD7FF)
+        if 0xE1 <= b <= 0xEF: return ((b & 0xF) << 12, ((b & 0xF) << 12) + 0xFFF)
+        if b == 0xF0: return (0x10000, 0x3FFFF)
+        if 0xF1 <= b <= 0xF3: return ((b & 7) << 18, ((b & 7) << 18) + 0x3FFFF)
+        if b == 0xF4: return (0x100000, 0x10FFFF)
+        return None
+    got = [b for b in range(256) if sim.sim_lead_all_letters(b)]
+    exp = []
+    for b in range(256):
+        r = rng(b)
+        if r and all(unicodedata.category(chr(c)).startswith("L") for c in range(r[0], r[1] + 1)):
+            exp.append(b)
+    assert got == exp
+    assert {0xD0, 0xD1, 0xE5, 0xE6, 0xE7, 0xE8, 0xEB, 0xEC} <= set(got) and 0xE4 not in got and 0xE9 not in got
+
+
 @pytest.mark.parametrize("kind", [1, 0])
 def test_block_classification_matches_per_byte_rules(sim, kind):
     """jtk_block_classify.h (one lane classifies 64 bytes: flag table + shift-or accumulation, 'all letters' lead bytes,
