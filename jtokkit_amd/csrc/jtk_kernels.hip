@@ -432,7 +432,13 @@ __host__ __device__ __forceinline__ constexpr int q_off(int bin) {
 }
 constexpr int Q_TOTAL = q_off(JTK_BIN_TINY) + JTK_TINY_CAP;
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
+#ifndef JTK_RES_WAVES
+#define JTK_RES_WAVES 4
+#endif
+constexpr int RES_WAVES = JTK_RES_WAVES, RES_THREADS = 64 * RES_WAVES;   // waves per tile
+static_assert(RES_THREADS >= (T + 16) / 16 && RES_THREADS > 64, "the prologue's lane roles");
+
+__global__ void __launch_bounds__(RES_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_piece_resolve(JtkWork w, JtkDeviceTables t) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tx[T + 16];
     __shared__ uint16_t s_plist[T + 1];
     __shared__ uint64_t s_pm[TW];
@@ -491,7 +497,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const uint32_t inc = wave_incl_scan(c);
         np = (int)(uint32_t)__shfl((int)inc, 63);
         const uint32_t pre = inc - c;
-        for (int wd = wv; wd < TW; wd += 4) {
+        for (int wd = wv; wd < TW; wd += RES_WAVES) {
             const uint64_t m = s_pm[wd];
             const uint32_t base = (uint32_t)__shfl((int)pre, wd);
             if ((m >> lane) & 1ull)
@@ -625,12 +631,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         }
         plist[k] = entry;
     };
-    // Pieces are taken in chunks of 64 (chunk c: pieces 64 c .. 64 c + 63); wave wv takes chunks wv, wv + 4, wv + 8, ... two at
+    // Pieces are taken in chunks of 64 (chunk c: pieces 64 c .. 64 c + 63); wave wv takes chunks wv, wv + RES_WAVES, ... two at
     // a time while there are two (so that two probes per lane are in flight), one otherwise: a tile of 530 pieces costs nine
     // chunk passes, not the sixteen of two full rounds of 512.
-    for (int c0 = wv; c0 * 64 < np; c0 += 8) {
-        const bool two = (c0 + 4) * 64 < np;                               // wave-uniform
-        const int ka = c0 * 64 + lane, kb = (c0 + 4) * 64 + lane;
+    for (int c0 = wv; c0 * 64 < np; c0 += 2 * RES_WAVES) {
+        const bool two = (c0 + RES_WAVES) * 64 < np;                       // wave-uniform
+        const int ka = c0 * 64 + lane, kb = (c0 + RES_WAVES) * 64 + lane;
         Probe p0, p1;
         issue(ka, p0);
         if (two) issue(kb, p1); else { p1.s = 0; p1.len = 0; p1.ka = make_uint4(0, 0, 0, 0); p1.ma = make_uint2(0, 0); p1.k0 = p1.k1 = p1.k2 = p1.k3 = p1.mix = 0; }
@@ -678,7 +684,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         }
     }
     if (all_waves) __syncthreads(); else wave_lds_fence();
-    const int nthr = all_waves ? 256 : WAVE, me = all_waves ? tid : lane;
+    const int nthr = all_waves ? RES_THREADS : WAVE, me = all_waves ? tid : lane;
 #pragma unroll
     for (int q = 0; q < JTK_NBINS_BYTES; q++) {   // bins of <= 16 bytes: bytes + meta
         const uint32_t nq0 = s_qn[q];
@@ -2014,7 +2020,7 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
     else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
 }
 void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(256), 0, s, w, t);
+    hipLaunchKernelGGL(k_piece_resolve, dim3((unsigned)w.n_tiles), dim3(RES_THREADS), 0, s, w, t);
 }
 void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     if (t.longtok.n) hipLaunchKernelGGL(k_long_shortcut, dim3(256), dim3(256), 0, s, w, t);
