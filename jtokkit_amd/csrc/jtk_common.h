@@ -155,6 +155,9 @@ JTK_HD uint32_t jtk_bp_lookup(const JtkBpLds& t, uint32_t idx) {
 // slot carries the overflow flag.
 #define JTK_TOK_OVERFLOW 0x80000000u        // in len: a key whose primary slot this is lives in its secondary slot
 #define JTK_TOK_LEN_MASK 0xFFu
+// ... and which: bits 8..23 of len are a 16-bit filter over the low four bits of those keys' mixes, so that a key that is
+// not in the table at all (every piece that has to be merged) seldom has to look at its secondary slot to learn so
+#define JTK_TOK_FILTER_BIT(mix) (1u << (8u + ((mix) & 15u)))
 struct JtkTok8Slot {
     uint32_t lo, hi, id, len;       // len & JTK_TOK_LEN_MASK == 0: empty
 };

@@ -577,7 +577,8 @@ __global__ void __launch_bounds__(RES_THREADS) __attribute__((amdgpu_waves_per_e
         const uint32_t diff = (pr.ka.x ^ pr.k0) | (pr.ka.y ^ pr.k1) | ((slen & JTK_TOK_LEN_MASK) ^ pr.len) |
                               (small ? 0u : ((pr.ka.z ^ pr.k2) | (pr.ka.w ^ pr.k3)));
         id = diff == 0u ? (small ? pr.ka.z : pr.ma.x) : JTK_RANK_NONE;
-        more = diff != 0u && (slen & JTK_TOK_OVERFLOW) != 0u && pr.len - 1u < 16u;
+        // (the slot's filter says whether a key with this mix can be among those it turned away)
+        more = diff != 0u && (slen & JTK_TOK_FILTER_BIT(pr.mix)) != 0u && pr.len - 1u < 16u;
     };
     auto issue2 = [&](Probe& pr) {                                       // secondary slot
         const bool small = pr.len <= 8u;

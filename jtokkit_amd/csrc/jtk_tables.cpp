@@ -268,7 +268,10 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
             t.tok8_displaced = 0;
             for (size_t i = 0; i < shorts.size(); i++) t.tok8[where[i]] = shorts[i];
             for (size_t i = 0; i < shorts.size(); i++)
-                if (where[i] != h1[i]) { t.tok8[h1[i]].len |= JTK_TOK_OVERFLOW; t.tok8_displaced++; }
+                if (where[i] != h1[i]) {
+                    t.tok8[h1[i]].len |= JTK_TOK_OVERFLOW | JTK_TOK_FILTER_BIT(jtk_tok16_mix(shorts[i].lo, shorts[i].hi, 0u, 0u, shorts[i].len));
+                    t.tok8_displaced++;
+                }
             break;
         }
     }
@@ -297,7 +300,8 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
             t.tok16.assign(ns, JtkTok16Slot{{0, 0, 0, 0}, 0, 0, 0, 0});
             for (size_t i = 0; i < mids.size(); i++) t.tok16[where[i]] = mids[i];
             for (size_t i = 0; i < mids.size(); i++)
-                if (where[i] != h1[i]) t.tok16[h1[i]].len |= JTK_TOK_OVERFLOW;
+                if (where[i] != h1[i])
+                    t.tok16[h1[i]].len |= JTK_TOK_OVERFLOW | JTK_TOK_FILTER_BIT(jtk_tok16_mix(mids[i].k[0], mids[i].k[1], mids[i].k[2], mids[i].k[3], mids[i].len));
             break;
         }
     }
