@@ -45,8 +45,8 @@ struct DevBuf {
 };
 
 constexpr int N_STAGES = 8;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "piece_resolve", "bpe_merge",
-                                           "tile_scan", "pack", "doc_offsets"};
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "long_pieces", "strip_encode",
+                                           "tile_scan", "strip_gather", "doc_offsets"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -72,7 +72,7 @@ struct ChunkSet {
     hipEvent_t ev_scan = nullptr;    // this set's tile_scan has run (the next chunk's scan waits for it: token order)
     hipEvent_t ev_done = nullptr;    // this set's last kernel has run
     DevBuf zeroed;                   // docmask | list counters | queue counters
-    DevBuf piecemask, gapmask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list, giant_list, giant_cnt;
+    DevBuf piecemask, gapmask, stok, htok, docpre, tile_tot, tile_off, queues, mid_list, long_list, giant_list;
     JtkWork work{};
     bool used = false;               // by the current job
 };
@@ -304,8 +304,8 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ChunkSet& cs : b->set) {
         if (cs.stream) (void)hipStreamSynchronize(cs.stream);
-        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.plist, &cs.htok, &cs.docpre, &cs.tile_np, &cs.tile_off, &cs.queues, &cs.q_meta,
-                          &cs.mid_list, &cs.long_list, &cs.giant_list, &cs.giant_cnt};
+        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.stok, &cs.htok, &cs.docpre, &cs.tile_tot, &cs.tile_off, &cs.queues,
+                          &cs.mid_list, &cs.long_list, &cs.giant_list};
         for (DevBuf* d : bufs) d->release();
         if (cs.ev_scan) (void)hipEventDestroy(cs.ev_scan);
         if (cs.ev_done) (void)hipEventDestroy(cs.ev_done);
@@ -389,22 +389,23 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t nt = (size_t)w.n_tiles;
-    const size_t qcnt_bytes = (JTK_NBINS + 1) * JTK_Q_SHARDS * 4;
+    const size_t qcnt_bytes = JTK_NBINS * JTK_Q_SHARDS * 4;
     const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
     const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
+    const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3};
+    size_t q_bytes = 0;
+    for (int k = 0; k < JTK_NBINS; k++) q_bytes += tps * caps[k] * JTK_Q_SHARDS * 8;
     int rc;
     if ((rc = cs.zeroed.ensure(zero_bytes)) || (rc = cs.piecemask.ensure(mask_bytes)) ||
-        (rc = cs.plist.ensure(nt * JTK_TILE * 4)) || (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
-        (rc = cs.docpre.ensure(nt * JTK_TILE * 4)) ||
-        (rc = cs.tile_np.ensure(align_up(nt * 4, 16) * 2)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
-        (rc = cs.q_meta.ensure(nt * 4 * 16)) ||
-        (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * ((size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4 + JTK_BIN_CAP5 + JTK_BIN_CAP6) * 24 + (size_t)JTK_TINY_CAP * 8))) ||
+        (rc = cs.stok.ensure(nt * JTK_TILE * 4)) || (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
+        (rc = cs.docpre.ensure(nt * JTK_TILE * 4 + 64)) ||
+        (rc = cs.tile_tot.ensure(align_up(nt * 4, 16) + 16)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
+        (rc = cs.queues.ensure(q_bytes)) ||
         (rc = cs.mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
-        (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
-        (rc = cs.giant_cnt.ensure(n_giant_max * 4)))
+        (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))))
         return rc;
     uint8_t* z = (uint8_t*)cs.zeroed.p;
     w.docmask = (uint64_t*)z;
@@ -413,29 +414,19 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.n_giant = (uint32_t*)(z + mask_bytes + 8);
     w.q_count = (uint32_t*)(z + mask_bytes + 32);
     w.piecemask = (uint64_t*)cs.piecemask.p;
-    w.plist = (uint32_t*)cs.plist.p;
+    w.stok = (uint32_t*)cs.stok.p;
     w.htok = (uint32_t*)cs.htok.p;
     w.docpre = (uint32_t*)cs.docpre.p;
-    w.tile_np = (uint32_t*)cs.tile_np.p;
-    w.tile_tot = (uint32_t*)((uint8_t*)cs.tile_np.p + align_up(nt * 4, 16));
+    w.tile_tot = (uint32_t*)cs.tile_tot.p;
     w.tile_off = (int64_t*)cs.tile_off.p;
     {
-        const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4, JTK_BIN_CAP5, JTK_BIN_CAP6};
-        uint8_t* qp = (uint8_t*)cs.queues.p;                      // all the 16-byte arrays first, then the 8-byte ones
-        w.q_meta = (uint32_t*)cs.q_meta.p;
-        for (int k = 0; k < JTK_NBINS; k++) {
-            w.qd[k] = (uint4*)qp;
-            w.q_cap[k] = (int64_t)(tps * caps[k]);
-            qp += tps * caps[k] * JTK_Q_SHARDS * 16;
-        }
+        uint8_t* qp = (uint8_t*)cs.queues.p;
         for (int k = 0; k < JTK_NBINS; k++) {
             w.qm[k] = (uint64_t*)qp;
+            w.q_cap[k] = (int64_t)(tps * caps[k]);
             qp += tps * caps[k] * JTK_Q_SHARDS * 8;
         }
-        w.qt = (uint64_t*)qp;
-        w.qt_cap = (int64_t)(tps * JTK_TINY_CAP);
     }
-    w.giant_cnt = (uint32_t*)cs.giant_cnt.p;
     w.mid_list = (JtkLongPiece*)cs.mid_list.p;
     w.long_list = (JtkLongPiece*)cs.long_list.p;
     w.giant_list = (JtkLongPiece*)cs.giant_list.p;
@@ -585,12 +576,13 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
             jtk_launch_pretok_split(w, enc->dt, cst);
         }
         end();
-        begin();
-        jtk_launch_piece_resolve(w, enc->dt, cst);
-        end();
-        begin();
+        begin();                                                    // pieces of more than 16 bytes: listed, merged, tokens in htok
+        jtk_launch_find_long(w, cst);
         jtk_launch_long_shortcut(w, enc->dt, cst);                  // (only for rank tables with entries merging cannot reproduce)
         jtk_launch_bpe_merge(w, enc->dt, cst);
+        end();
+        begin();                                                    // every strip: pieces -> tokens (dense per strip) + its count
+        jtk_launch_strip_encode(w, enc->dt, cst);
         end();
         begin();
         if (fork && c > 0) HIP_TRY(hipStreamWaitEvent(cst, b->set[(c - 1) % n_sets].ev_scan, 0));
@@ -598,7 +590,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         if (fork) HIP_TRY(hipEventRecord(cs.ev_scan, cst));
         end();
         begin();
-        jtk_launch_pack(w, cst);
+        jtk_launch_strip_gather(w, cst);
         end();
         begin();
         jtk_launch_doc_offsets(w, cst);
