@@ -602,3 +602,12 @@ void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w);
 }
 
+#ifdef JTK_ENC_STAMP
+// diagnostic build (tools/enc_stamps.py): the encode kernel's phase cycles since the last call
+extern "C" int jtk_debug_stamps(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_enc_stamp), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_enc_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+

@@ -18,45 +18,73 @@ __device__ __forceinline__ uint64_t piece_word(const JtkWork& w, int64_t wd) {
     return m;
 }
 
+__device__ __forceinline__ uint32_t mbcnt64_(uint64_t m) {          // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 __global__ void __launch_bounds__(256) k_find_long(JtkWork w) {
+    // (a wave covers 64 consecutive mask words = one tile, so all its pieces go to the same queue shard: the wave claims its
+    // entries with ONE returning atomic per length class and round -- a lane holds at most four such pieces -- instead of
+    // one per piece: text with many long pieces made 2.6 ms of contended atomics out of 128 MB)
     const int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int64_t n = w.n_bytes;
-    if (wd * 64 >= n) return;
-    uint64_t m = piece_word(w, wd);
-    const uint64_t nx = piece_word(w, wd + 1);
-    if (wd * 64 + 63 >= n) m &= (1ull << (n - wd * 64)) - 1ull;                 // the sentinel starts no piece
-    if (m == 0) return;
-    // x: bit p set iff one of the bits p + 1 .. p + 16 of (m, nx) is set  (smear down by 1, 2, 4, 8 after a shift of one)
-    const uint64_t all = piece_word(w, wd);                                       // with the sentinel: it ends pieces
-    uint64_t lo = (all >> 1) | (nx << 63), hi = nx >> 1;
-    lo |= (lo >> 1) | (hi << 63); hi |= hi >> 1;
-    lo |= (lo >> 2) | (hi << 62); hi |= hi >> 2;
-    lo |= (lo >> 4) | (hi << 60); hi |= hi >> 4;
-    lo |= (lo >> 8) | (hi << 56);
-    for (uint64_t lg = m & ~lo; lg;) {
-        const int p = jtk_ctz64(lg);
-        lg &= lg - 1;
-        const int64_t start = wd * 64 + p;
-        if (w.gapmask && ((w.gapmask[wd] >> p) & 1ull)) continue;                 // unmatched text: no tokens
-        // where the piece ends: the next set bit (the sentinel at n at the latest)
-        int64_t end = -1;
-        const uint64_t rest = p < 63 ? all & ~((2ull << p) - 1ull) : 0ull;
-        if (rest) end = wd * 64 + jtk_ctz64(rest);
-        for (int64_t v = wd + 1; end < 0 && v < w.n_words; v++) {
-            const uint64_t mv = piece_word(w, v);
-            if (mv) end = v * 64 + jtk_ctz64(mv);
+    uint64_t m = 0, all = 0, lo = 0;
+    if (wd * 64 < n) {
+        all = piece_word(w, wd);                                                  // with the sentinel: it ends pieces
+        m = all;
+        if (wd * 64 + 63 >= n) m &= (1ull << (n - wd * 64)) - 1ull;             // the sentinel starts no piece
+    }
+    if (!__ballot(m != 0)) return;
+    if (m) {
+        // lo: bit p set iff one of the bits p + 1 .. p + 16 of (all, next word) is set  (smear down by 1, 2, 4, 8 after a shift of one)
+        const uint64_t nx = piece_word(w, wd + 1);
+        uint64_t hi = nx >> 1;
+        lo = (all >> 1) | (nx << 63);
+        lo |= (lo >> 1) | (hi << 63); hi |= hi >> 1;
+        lo |= (lo >> 2) | (hi << 62); hi |= hi >> 2;
+        lo |= (lo >> 4) | (hi << 60); hi |= hi >> 4;
+        lo |= (lo >> 8) | (hi << 56);
+    }
+    uint64_t lg = m & ~lo;
+    if (lg && w.gapmask) lg &= ~w.gapmask[wd];                                    // unmatched text: no tokens
+    const int shard = (int)(((wd * 64) / T) % JTK_Q_SHARDS);
+    while (__ballot(lg != 0)) {
+        // this round: every lane's next long piece; cls: 0..3 queue bin, 4 mid, 5 long, 6 giant, 7 too long, 8 none
+        int cls = 8;
+        int64_t start = 0, len = 0;
+        if (lg) {
+            const int p = jtk_ctz64(lg);
+            lg &= lg - 1;
+            start = wd * 64 + p;
+            // where the piece ends: the next set bit (the sentinel at n at the latest)
+            int64_t end = -1;
+            const uint64_t rest = p < 63 ? all & ~((2ull << p) - 1ull) : 0ull;
+            if (rest) end = wd * 64 + jtk_ctz64(rest);
+            for (int64_t v = wd + 1; end < 0 && v < w.n_words; v++) {
+                const uint64_t mv = piece_word(w, v);
+                if (mv) end = v * 64 + jtk_ctz64(mv);
+            }
+            if (end < 0 || end > n) end = n;
+            len = end - start;
+            cls = len <= 32 ? 0 : len <= 64 ? 1 : len <= 128 ? 2 : len <= JTK_BIN_MAXLEN ? 3 : len <= JTK_MID_CAP ? 4 : len <= JTK_LONG_CAP ? 5
+                  : len <= JTK_GIANT_CAP ? 6 : 7;
         }
-        if (end < 0 || end > n) end = n;
-        const int64_t len = end - start;
-        if (len <= JTK_BIN_MAXLEN) {
-            const int bin = len <= 32 ? 0 : len <= 64 ? 1 : len <= 128 ? 2 : 3;
-            const int shard = (int)((start / T) % JTK_Q_SHARDS);
-            const uint32_t i = atomicAdd(&w.q_count[bin * JTK_Q_SHARDS + shard], 1u);
-            w.qm[bin][(int64_t)shard * w.q_cap[bin] + i] = (uint64_t)start | ((uint64_t)(len - 1) << JTK_QE_LEN_SHIFT);
-        } else if (len <= JTK_MID_CAP) w.mid_list[atomicAdd(w.mid_count, 1u)] = JtkLongPiece{start, len};
-        else if (len <= JTK_LONG_CAP) w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{start, len};
-        else if (len <= JTK_GIANT_CAP) w.giant_list[atomicAdd(w.n_giant, 1u)] = JtkLongPiece{start, len};
-        else {
+        for (uint64_t todo = __ballot(cls < 7); todo;) {
+            const int c = __builtin_amdgcn_readlane(cls, jtk_ctz64(todo));
+            const uint64_t mask = __ballot(cls == c);
+            todo &= ~mask;
+            uint32_t* counter = c < JTK_NBINS ? &w.q_count[c * JTK_Q_SHARDS + shard] : c == 4 ? w.mid_count : c == 5 ? w.long_count : w.n_giant;
+            uint32_t base = 0;
+            if (lane == jtk_ctz64(mask)) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, jtk_ctz64(mask));
+            if (cls == c) {
+                const uint32_t i = base + mbcnt64_(mask);
+                if (c < JTK_NBINS) w.qm[c][(int64_t)shard * w.q_cap[c] + i] = (uint64_t)start | ((uint64_t)(len - 1) << JTK_QE_LEN_SHIFT);
+                else (c == 4 ? w.mid_list : c == 5 ? w.long_list : w.giant_list)[i] = JtkLongPiece{start, len};
+            }
+        }
+        if (cls == 7) {
             // longer than the library accepts: the document gets a status, the piece no tokens
             const int64_t d = find_doc(w, start);
             if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);

@@ -28,7 +28,12 @@
 constexpr int ENC_WAVES = JTK_ENC_WAVES, ENC_THREADS = 64 * ENC_WAVES;
 constexpr int ENC_RING = 16;                   // chunks whose answers wait in registers
 constexpr int ENC_WIN = 1024;                  // piece starts listed in LDS at a time
-constexpr int ENC_PEND = 128;                  // pending hard pieces (a ring: at most 127 wait)
+#ifndef JTK_ENC_G
+#define JTK_ENC_G 2
+#endif
+constexpr int ENC_G = JTK_ENC_G;               // chunks resolved per step (loads in flight per lane)
+constexpr int ENC_PEND = 256;                  // pending hard pieces (a ring: at most 63 + 64 ENC_G wait)
+static_assert(63 + 64 * ENC_G < ENC_PEND && ENC_WIN % (64 * ENC_G) == 0, "pending ring / window");
 static_assert(T == 4096, "a strip is 64 mask words: one per lane");
 
 // ring word of a piece
@@ -42,7 +47,7 @@ struct __attribute__((aligned(16))) EncWaveLds {
     uint32_t id[16 * 64];                      // parts of the pieces being merged: token ids, [slot][lane] ...
     uint32_t rk[16 * 64];                      // ... and pair keys; after a round rk[lane] = the lane's live-part mask
     uint32_t pend[ENC_PEND];                   // pending hard pieces: piece index (12) | offset << 12 | (len - 1) << 24
-    uint16_t starts[ENC_WIN + 64];             // byte offsets of pieces k0 .. k0 + ENC_WIN (one more: where the last ends)
+    uint16_t starts[ENC_WIN + 8];             // byte offsets of pieces k0 .. k0 + ENC_WIN (one more: where the last ends)
 };
 
 struct __attribute__((packed, aligned(1))) U4Bytes { uint32_t x, y, z, w; };
@@ -69,9 +74,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {            // set bits of m below this lane
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) { return mbcnt64_(m); }
+
+#ifdef JTK_ENC_STAMP
+// diagnostic build: wave cycles per phase, summed over the launch (never read by the kernels; jtk_debug_stamps() fetches them)
+__device__ unsigned long long g_enc_stamp[16];
+#define STAMP_BEGIN() const uint64_t st_t0 = __builtin_amdgcn_s_memtime()
+#define STAMP_END(i) st_acc[i] += __builtin_amdgcn_s_memtime() - st_t0
+#define STAMP_ADD(i, v) st_acc[i] += (uint64_t)(v)
+#else
+#define STAMP_BEGIN()
+#define STAMP_END(i)
+#define STAMP_ADD(i, v)
+#endif
 
 __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDeviceTables t) {
     __shared__ uint64_t s_bpbits[1024];
@@ -95,6 +110,10 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
     const bool store = w.count_only == 0;
     const uint8_t* const tok = reinterpret_cast<const uint8_t*>(t.tok8.slots);   // the tok8 slots, then the tok16 slots: one allocation
     const uint32_t rel16 = (uint32_t)(reinterpret_cast<const uint8_t*>(t.tok16.slots) - tok);
+#ifdef JTK_ENC_STAMP
+    uint64_t st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t st_wave0 = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int64_t strip = (int64_t)wv * gridDim.x + blockIdx.x; strip < w.n_tiles; strip += (int64_t)gridDim.x * ENC_WAVES) {
         const int64_t B = strip * T;
@@ -104,6 +123,8 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
         if (wd * 64 + 63 >= n) pm &= (wd * 64 >= n) ? 0ull : ((1ull << (n - wd * 64)) - 1ull);
         const uint64_t gm = (gaps && wd < w.n_words) ? w.gapmask[wd] : 0ull;
         const uint64_t dm = (wd < w.n_words) ? w.docmask[wd] : 0ull;
+        // (touch the strip's text -- one word of every 64-byte block -- so that it is on its way while the masks are scanned)
+        const uint32_t touch = (B + lane * 64 < n) ? *reinterpret_cast<const uint32_t*>(w.text + B + lane * 64) : 0u;
         const uint32_t cnt = (uint32_t)__popcll(pm);
         const uint32_t inc = wave_incl_scan_dpp(cnt);
         const int np = (int)(uint32_t)__shfl((int)inc, 63);
@@ -138,8 +159,11 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
         uint32_t* const out = w.stok + B;
 
         while (k_pack < np) {
-            // ---- resolve chunks while the pending list is short of a full round and the ring has room
+            // ---- resolve chunks while the pending list is short of a full round and the ring has room: ENC_G chunks per
+            // step, so that a lane has ENC_G text loads and then ENC_G table probes in flight (what bounds this phase is the
+            // latency of those two dependent loads, not their number)
             while (k_res < np && pn_tail - pn_head < 64u && (k_res >> 6) - (k_pack >> 6) < ENC_RING) {
+                STAMP_BEGIN();
                 if (k_res >= k0 + ENC_WIN) {
                     // list the starts of pieces k0 .. k0 + ENC_WIN (each lane: the set bits of its word)
                     k0 += ENC_WIN;
@@ -152,68 +176,111 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
                     if (lane == 0 && np - k0 <= ENC_WIN) W.starts[np - k0] = (uint16_t)end_rel;
                     wave_lds_fence();
                 }
-                const int k = k_res + lane;
-                const bool have = k < np;
-                const int rel = have ? k - k0 : 0;
-                const uint32_t s = W.starts[rel], e = W.starts[rel + 1];
-                const uint32_t plen = have ? e - s : 0u;                         // (> 16: only "long" matters)
-                const bool shortp = plen <= (uint32_t)JTK_SHORT_MAX;
-                const uint32_t len = shortp ? plen : 0u;
-                // up to 16 bytes of the piece, zero beyond its length
-                const uint4 tx = load_text16(w.text, B + s, n);
-                const uint64_t runm = ~0ull >> ((0u - 8u * len) & 63u);          // 8 len ones (len 8 and 16: all 64)
-                const bool big = len > 8u;
-                const uint64_t mlo = big ? ~0ull : runm, mhi = big ? runm : 0ull;
-                const uint32_t key0 = tx.x & (uint32_t)mlo, key1 = tx.y & (uint32_t)(mlo >> 32);
-                const uint32_t key2 = tx.z & (uint32_t)mhi, key3 = tx.w & (uint32_t)(mhi >> 32);
-                // one mix for both tables and both choices; only base, slot size and slot count depend on the length
-                const uint32_t mix = jtk_tok16_mix(key0, key1, key2, key3, len);
-                auto slot_off = [&](uint32_t mx) -> uint32_t {
-                    const uint32_t h = jtk_reduce32(mx, big ? t.tok16.n : t.tok8.bits);
-                    return big ? (h << 5) + rel16 : (h << 4);
+                // chunks of this step: as many as the ring, the listed window and the strip allow
+                int g = ENC_RING - ((k_res >> 6) - (k_pack >> 6));
+                g = min(g, min((k0 + ENC_WIN - k_res) >> 6, (np - k_res + 63) >> 6));
+                g = min(g, ENC_G);
+                bool have[ENC_G], shortp[ENC_G], big[ENC_G];
+                uint32_t s[ENC_G], len[ENC_G], key0[ENC_G], key1[ENC_G], key2[ENC_G], key3[ENC_G], mix[ENC_G];
+                uint4 tx[ENC_G], ka[ENC_G];
+                uint2 ma[ENC_G];
+                // (chunks q >= g are computed too -- on piece 0, results dropped -- so that there is no branch between the loads)
+                bool tail = false;
+#pragma unroll
+                for (int q = 0; q < ENC_G; q++) {
+                    const int k = k_res + 64 * q + lane;
+                    have[q] = q < g && k < np;
+                    const int rel = have[q] ? k - k0 : 0;
+                    const uint32_t e = W.starts[rel + 1];
+                    s[q] = W.starts[rel];
+                    const uint32_t plen = have[q] ? e - s[q] : 0u;                   // (> 16: only "long" matters)
+                    shortp[q] = plen <= (uint32_t)JTK_SHORT_MAX;
+                    len[q] = shortp[q] ? plen : 0u;
+                    tail = tail || B + s[q] + 16 > n;
+                }
+                // up to 16 bytes of every piece: one unaligned load each, back to back (only the last bytes of the text need care)
+                if (!__ballot(tail)) {
+#pragma unroll
+                    for (int q = 0; q < ENC_G; q++) {
+                        const U4Bytes v = *reinterpret_cast<const U4Bytes*>(w.text + B + s[q]);
+                        tx[q] = make_uint4(v.x, v.y, v.z, v.w);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < ENC_G; q++) tx[q] = load_text16(w.text, B + s[q], n);
+                }
+                auto slot_off = [&](int q, uint32_t mx) -> uint32_t {
+                    const uint32_t h = jtk_reduce32(mx, big[q] ? t.tok16.n : t.tok8.bits);
+                    return big[q] ? (h << 5) + rel16 : (h << 4);
                 };
-                auto probe = [&](uint32_t mx, uint32_t& idv, bool& more) {
-                    const uint8_t* sa = tok + slot_off(mx);
-                    const uint4 ka = *reinterpret_cast<const uint4*>(sa);        // tok8: lo, hi, id, len; tok16: the 16 key bytes
-                    uint2 ma = make_uint2(0, 0);
-                    if (big) ma = *reinterpret_cast<const uint2*>(sa + 16);      // tok16: id, len
-                    const uint32_t slen = big ? ma.y : ka.w;
-                    const uint32_t diff = (ka.x ^ key0) | (ka.y ^ key1) | ((slen & JTK_TOK_LEN_MASK) ^ len) |
-                                          (big ? ((ka.z ^ key2) | (ka.w ^ key3)) : 0u);
-                    idv = diff == 0u ? (big ? ma.x : ka.z) : JTK_RANK_NONE;
+#pragma unroll
+                for (int q = 0; q < ENC_G; q++) {
+                    const uint64_t runm = ~0ull >> ((0u - 8u * len[q]) & 63u);       // 8 len ones (len 8 and 16: all 64)
+                    big[q] = len[q] > 8u;
+                    const uint64_t mlo = big[q] ? ~0ull : runm, mhi = big[q] ? runm : 0ull;
+                    key0[q] = tx[q].x & (uint32_t)mlo; key1[q] = tx[q].y & (uint32_t)(mlo >> 32);
+                    key2[q] = tx[q].z & (uint32_t)mhi; key3[q] = tx[q].w & (uint32_t)(mhi >> 32);
+                    // one mix for both tables and both choices; only base, slot size and slot count depend on the length
+                    mix[q] = jtk_tok16_mix(key0[q], key1[q], key2[q], key3[q], len[q]);
+                    const uint8_t* sa = tok + slot_off(q, mix[q]);
+                    ka[q] = *reinterpret_cast<const uint4*>(sa);                     // tok8: lo, hi, id, len; tok16: the 16 key bytes
+                    ma[q] = make_uint2(0, 0);
+                    if (big[q]) ma[q] = *reinterpret_cast<const uint2*>(sa + 16);    // tok16: id, len
+                }
+                auto check = [&](int q, uint32_t& idv, bool& more) {
+                    const uint32_t slen = big[q] ? ma[q].y : ka[q].w;
+                    const uint32_t diff = (ka[q].x ^ key0[q]) | (ka[q].y ^ key1[q]) | ((slen & JTK_TOK_LEN_MASK) ^ len[q]) |
+                                          (big[q] ? ((ka[q].z ^ key2[q]) | (ka[q].w ^ key3[q])) : 0u);
+                    idv = diff == 0u ? (big[q] ? ma[q].x : ka[q].z) : JTK_RANK_NONE;
                     // (the slot's filter says whether a key with this mix can be among those it turned away)
-                    more = diff != 0u && (slen & JTK_TOK_FILTER_BIT(mix)) != 0u;
+                    more = diff != 0u && (slen & JTK_TOK_FILTER_BIT(mix[q])) != 0u && len[q] != 0u;
                 };
-                uint32_t tid_ = JTK_RANK_NONE;
-                bool more = false;
-                probe(mix, tid_, more);
-                more = more && len != 0u;
-                if (__ballot(more)) {
-                    uint32_t id2 = JTK_RANK_NONE;
-                    bool dummy;
-                    if (more) { probe(jtk_pair_mix2(mix), id2, dummy); tid_ = id2; }
+                uint32_t tokid[ENC_G];
+                bool more[ENC_G], any_more = false;
+#pragma unroll
+                for (int q = 0; q < ENC_G; q++) { check(q, tokid[q], more[q]); any_more = any_more || more[q]; }
+                if (__ballot(any_more)) {                                            // secondary slots, for the lanes that need them
+#pragma unroll
+                    for (int q = 0; q < ENC_G; q++) {
+                        if (more[q]) {
+                            const uint8_t* sa = tok + slot_off(q, jtk_pair_mix2(mix[q]));
+                            ka[q] = *reinterpret_cast<const uint4*>(sa);
+                            if (big[q]) ma[q] = *reinterpret_cast<const uint2*>(sa + 16);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < ENC_G; q++) { bool dummy; if (more[q]) check(q, tokid[q], dummy); }
                 }
-                bool gap = false;
-                if (gaps) {                                                      // (wave-uniform; the shuffles are evaluated by all lanes)
-                    const uint32_t glo = (uint32_t)__shfl((int)(uint32_t)gm, (int)(s >> 6)), ghi = (uint32_t)__shfl((int)(uint32_t)(gm >> 32), (int)(s >> 6));
-                    gap = have && (((s & 32u) ? ghi : glo) >> (s & 31u)) & 1u;
+#pragma unroll
+                for (int q = 0; q < ENC_G; q++) {
+                    bool gap = false;
+                    if (gaps) {                                                      // (wave-uniform; the shuffles are evaluated by all lanes)
+                        const uint32_t glo = (uint32_t)__shfl((int)(uint32_t)gm, (int)(s[q] >> 6)), ghi = (uint32_t)__shfl((int)(uint32_t)(gm >> 32), (int)(s[q] >> 6));
+                        gap = have[q] && (((s[q] & 32u) ? ghi : glo) >> (s[q] & 31u)) & 1u;
+                    }
+                    const uint32_t dlo = (uint32_t)__shfl((int)(uint32_t)dm, (int)(s[q] >> 6)), dhi = (uint32_t)__shfl((int)(uint32_t)(dm >> 32), (int)(s[q] >> 6));
+                    const bool isdoc = have[q] && (((s[q] & 32u) ? dhi : dlo) >> (s[q] & 31u)) & 1u;
+                    const bool hit = have[q] && shortp[q] && tokid[q] != JTK_RANK_NONE && !gap;
+                    const bool hard = have[q] && shortp[q] && !hit && !gap;
+                    const uint64_t hb = __ballot(hard);
+                    const uint32_t pidx = pn_tail + mbcnt64(hb);
+                    if (hard) W.pend[pidx & (ENC_PEND - 1)] = (uint32_t)(k_res + 64 * q + lane) | (s[q] << 12) | ((len[q] - 1u) << 24);
+                    pn_tail += (uint32_t)__popcll(hb);
+                    const uint32_t kind = gap ? RW_GAP : hit ? RW_TOKEN : hard ? RW_HARD : RW_LONG;
+                    const uint32_t pay = hit ? tokid[q] : (pidx & (ENC_PEND - 1));
+                    if (q < g)
+                        ring[__builtin_amdgcn_readfirstlane(((k_res >> 6) + q) & (ENC_RING - 1))] = s[q] | (isdoc ? RW_DOC : 0u) | (kind << RW_KIND_SHIFT) | (pay << RW_PAY_SHIFT);
                 }
-                const uint32_t dlo = (uint32_t)__shfl((int)(uint32_t)dm, (int)(s >> 6)), dhi = (uint32_t)__shfl((int)(uint32_t)(dm >> 32), (int)(s >> 6));
-                const bool isdoc = have && (((s & 32u) ? dhi : dlo) >> (s & 31u)) & 1u;
-                const bool hit = have && shortp && tid_ != JTK_RANK_NONE && !gap;
-                const bool hard = have && shortp && !hit && !gap;
-                const uint64_t hb = __ballot(hard);
-                const uint32_t pidx = pn_tail + mbcnt64(hb);
-                if (hard) W.pend[pidx & (ENC_PEND - 1)] = (uint32_t)k | (s << 12) | ((len - 1u) << 24);
-                pn_tail += (uint32_t)__popcll(hb);
-                const uint32_t kind = gap ? RW_GAP : hit ? RW_TOKEN : hard ? RW_HARD : RW_LONG;
-                const uint32_t pay = hit ? tid_ : (pidx & (ENC_PEND - 1));
-                ring[__builtin_amdgcn_readfirstlane((k_res >> 6) & (ENC_RING - 1))] = s | (isdoc ? RW_DOC : 0u) | (kind << RW_KIND_SHIFT) | (pay << RW_PAY_SHIFT);
-                k_res += 64;
+                k_res += 64 * g;
+                STAMP_END(1);
+                STAMP_ADD(4, g);
             }
             // ---- one merge round: a lane per pending piece (GptBytePairEncoding.java:200-275)
             const uint32_t nround = min(64u, pn_tail - pn_head);
             if (nround) {
+                STAMP_BEGIN();
+                STAMP_ADD(5, 1);
+                STAMP_ADD(6, nround);
                 wave_lds_fence();                                                // the pending entries; the last round's results are consumed
                 const bool mine = (uint32_t)lane < nround;
                 const uint32_t pe = mine ? W.pend[(pn_head + (uint32_t)lane) & (ENC_PEND - 1)] : 0u;
@@ -234,12 +301,15 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
                 wave_lds_fence();
                 round_base = pn_head;
                 pn_head += nround;
+                STAMP_END(2);
             }
             // ---- pack every piece before the first one that still waits for a merge round
             int k_bound = k_res < np ? k_res : np;
             if (pn_head != pn_tail) k_bound = (int)(W.pend[pn_head & (ENC_PEND - 1)] & 0xFFFu);
             k_bound = __builtin_amdgcn_readfirstlane(k_bound);
+            STAMP_BEGIN();
             for (int c = k_pack >> 6; c * 64 < k_bound; c++) {
+                STAMP_ADD(7, 1);
                 const int k = c * 64 + lane;
                 const bool act = k >= k_pack && k < k_bound;
                 const uint32_t rw = ring[__builtin_amdgcn_readfirstlane(c & (ENC_RING - 1))];
@@ -291,10 +361,18 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
                 if (__ballot(act && (rw & RW_DOC))) { if (act && (rw & RW_DOC)) w.docpre[B + s] = pos; }
                 run += total;
             }
+            STAMP_END(3);
             k_pack = k_bound;
         }
+        asm volatile("" ::"v"(touch));
         if (lane == 0) w.tile_tot[strip] = run;
+        STAMP_ADD(8, 1);
+        STAMP_ADD(9, np);
     }
+#ifdef JTK_ENC_STAMP
+    st_acc[0] = __builtin_amdgcn_s_memtime() - st_wave0;
+    if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_enc_stamp[i], (unsigned long long)st_acc[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,50 @@
+"""Where k_strip_encode's wave time goes, by kind of text -- needs a library built with -DJTK_ENC_STAMP
+(tools/build_variants.sh stamp:"-DJTK_ENC_STAMP"; JTOKKIT_AMD_LIB=tools/variants/stamp.so python tools/enc_stamps.py)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mb", type=int, default=64)
+    args = ap.parse_args()
+    import torch
+    import jtokkit_amd
+    from jtokkit_amd import corpus, _native
+    lib = _native.lib()
+    lib.jtk_debug_stamps.restype = C.c_int
+    lib.jtk_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
+    enc = jtokkit_amd.get_encoding("cl100k_base", device=0)
+    n_docs = args.mb * 1000000 // 4096
+    buf = (C.c_ulonglong * 16)()
+    for name in ("_english_stream", "_cjk_stream", "_multiscript_stream", "_emoji_stream", "_code_stream"):
+        rng = np.random.default_rng(7)
+        stream = getattr(corpus, name)(rng, int(n_docs * 4096 * 1.05) + 4 * 32768)
+        text, off = corpus._assemble(rng, [stream], [n_docs], 4096, 256, 32768)
+        d_text = torch.from_numpy(text).cuda()
+        d_off = torch.from_numpy(off).cuda()
+        b = enc.new_batch()
+        b.set_profiling(True)
+        b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(off) - 1, len(text), ordinary=False, sync=True)
+        lib.jtk_debug_stamps(buf)
+        b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(off) - 1, len(text), ordinary=False, sync=True)
+        lib.jtk_debug_stamps(buf)
+        v = [int(x) for x in buf]
+        tot, res, mrg, pck = v[0], v[1], v[2], v[3]
+        strips, pieces = max(1, v[8]), v[9]
+        print("%-20s strip_encode %.3f ms | wave time: resolve %.0f%% merge %.0f%% pack %.0f%% other %.0f%% | per strip: %.0f pieces, %.1f resolve chunks, "
+              "%.2f rounds (%.0f%% of lanes), %.1f pack chunks, %.0f kcycles" % (
+                  name, b.kernel_times()["strip_encode"], 100.0 * res / tot, 100.0 * mrg / tot, 100.0 * pck / tot, 100.0 * (tot - res - mrg - pck) / tot,
+                  pieces / strips, v[4] / strips, v[5] / strips, 100.0 * v[6] / max(1, 64 * v[5]), v[7] / strips, (res + mrg + pck) / strips / 1e3), flush=True)
+        del b, d_text, d_off
+
+
+if __name__ == "__main__":
+    main()

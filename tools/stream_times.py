@@ -14,6 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mb", type=int, default=128)
     ap.add_argument("--encoding", default="cl100k_base")
+    ap.add_argument("--only", default=None, help="one stream: english, cjk, multiscript, emoji, code")
     args = ap.parse_args()
     import torch
     import jtokkit_amd
@@ -21,6 +22,8 @@ def main():
     enc = jtokkit_amd.get_encoding(args.encoding, device=0)
     n_docs = args.mb * 1000000 // 4096
     for name in ("_english_stream", "_cjk_stream", "_multiscript_stream", "_emoji_stream", "_code_stream"):
+        if args.only and name != "_%s_stream" % args.only:
+            continue
         rng = np.random.default_rng(7)
         stream = getattr(corpus, name)(rng, int(n_docs * 4096 * 1.05) + 4 * 32768)
         text, off = corpus._assemble(rng, [stream], [n_docs], 4096, 256, 32768)
