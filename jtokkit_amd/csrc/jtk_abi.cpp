@@ -46,7 +46,7 @@ struct DevBuf {
 
 constexpr int N_STAGES = 8;
 const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "long_pieces", "strip_encode",
-                                           "tile_scan", "strip_gather", "doc_offsets"};
+                                           "tile_scan", "strip_expand", "doc_offsets"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -72,13 +72,15 @@ struct ChunkSet {
     hipEvent_t ev_scan = nullptr;    // this set's tile_scan has run (the next chunk's scan waits for it: token order)
     hipEvent_t ev_done = nullptr;    // this set's last kernel has run
     DevBuf zeroed;                   // docmask | list counters | queue counters
-    DevBuf piecemask, gapmask, stok, htok, docpre, tile_tot, tile_off, queues, mid_list, long_list, giant_list;
+    DevBuf piecemask, gapmask, stok, hrec, holebits, htok, docpre, tile_tot, tile_off, queues, mid_list, long_list, giant_list;
     JtkWork work{};
     bool used = false;               // by the current job
 };
 
 constexpr int MAX_SETS = 4;
 constexpr int64_t SMALL_JOB_BYTES = 1 << 20;
+constexpr int64_t MEMO_MIN_JOB_BYTES = 4 << 20;   // smaller jobs merge every piece: clearing the memo would cost more than it saves
+constexpr uint32_t MEMO_SLOTS = 1u << 15;         // per XCD, 32 bytes each
 constexpr int64_t TINY_JOB_BYTES = 128 << 10;     // host jobs this small are staged so that offsets and text go down in one copy
 
 struct jtk_batch {
@@ -101,6 +103,7 @@ struct jtk_batch {
     DevBuf out;
     struct View { void* p = nullptr; };
     View job, status, tok_off, tokens;   // where those parts are in `out` for the last job
+    DevBuf memo;                     // merged pieces remembered during a job (per XCD; jtk_strip_encode.h), cleared per job
     DevBuf plan;                     // chunk plan of a device-resident batch
     int64_t* host_plan = nullptr;    // pinned
     size_t host_plan_cap = 0;
@@ -304,14 +307,14 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ChunkSet& cs : b->set) {
         if (cs.stream) (void)hipStreamSynchronize(cs.stream);
-        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.stok, &cs.htok, &cs.docpre, &cs.tile_tot, &cs.tile_off, &cs.queues,
+        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.stok, &cs.hrec, &cs.holebits, &cs.htok, &cs.docpre, &cs.tile_tot, &cs.tile_off, &cs.queues,
                           &cs.mid_list, &cs.long_list, &cs.giant_list};
         for (DevBuf* d : bufs) d->release();
         if (cs.ev_scan) (void)hipEventDestroy(cs.ev_scan);
         if (cs.ev_done) (void)hipEventDestroy(cs.ev_done);
         if (cs.stream) (void)hipStreamDestroy(cs.stream);
     }
-    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->in_pieces, &b->out, &b->plan, &b->dec_in_ids, &b->dec_in_off,
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->in_pieces, &b->out, &b->memo, &b->plan, &b->dec_in_ids, &b->dec_in_off,
                       &b->dec_zero, &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag};
     for (DevBuf* d : bufs) d->release();
     for (hipEvent_t ev : b->prof_ev) (void)hipEventDestroy(ev);
@@ -390,7 +393,8 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t nt = (size_t)w.n_tiles;
     const size_t qcnt_bytes = JTK_NBINS * JTK_Q_SHARDS * 4;
-    const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes;
+    const size_t tot_bytes = align_up(nt * 4, 16);                  // tile_tot: zeroed with the masks and counters
+    const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes + tot_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
     const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
@@ -399,7 +403,8 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     for (int k = 0; k < JTK_NBINS; k++) q_bytes += tps * caps[k] * JTK_Q_SHARDS * 8;
     int rc;
     if ((rc = cs.zeroed.ensure(zero_bytes)) || (rc = cs.piecemask.ensure(mask_bytes)) ||
-        (rc = cs.stok.ensure(nt * JTK_TILE * 4)) || (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
+        (rc = cs.stok.ensure(nt * JTK_TILE * 4)) || (rc = cs.hrec.ensure(nt * JTK_TILE * 8)) || (rc = cs.holebits.ensure(nt * 64 * 8)) ||
+        (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
         (rc = cs.docpre.ensure(nt * JTK_TILE * 4 + 64)) ||
         (rc = cs.tile_tot.ensure(align_up(nt * 4, 16) + 16)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
         (rc = cs.queues.ensure(q_bytes)) ||
@@ -417,7 +422,10 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.stok = (uint32_t*)cs.stok.p;
     w.htok = (uint32_t*)cs.htok.p;
     w.docpre = (uint32_t*)cs.docpre.p;
-    w.tile_tot = (uint32_t*)cs.tile_tot.p;
+    w.tile_tot = (uint32_t*)(z + mask_bytes + 32 + qcnt_bytes);
+    w.tile_np = (uint32_t*)cs.tile_tot.p;
+    w.hrec = (uint64_t*)cs.hrec.p;
+    w.holebits = (uint64_t*)cs.holebits.p;
     w.tile_off = (int64_t*)cs.tile_off.p;
     {
         uint8_t* qp = (uint8_t*)cs.queues.p;
@@ -481,6 +489,15 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         const size_t need = (size_t)n_chunks * N_STAGES * 2;
         while (b->prof_ev.size() < need) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); b->prof_ev.push_back(ev); }
     }
+    // the memo of merged pieces: worth its clearing for jobs of some size
+    uint4* d_memo = nullptr;
+    if (n_bytes >= MEMO_MIN_JOB_BYTES && !getenv("JTK_NO_MEMO")) {
+        const size_t memo_bytes = (size_t)8 * MEMO_SLOTS * 32;
+        if ((rc = b->memo.ensure(memo_bytes))) return rc;
+        HIP_TRY(hipMemsetAsync(b->memo.p, 0, memo_bytes, s));
+        d_memo = (uint4*)b->memo.p;
+    }
+
     const bool fork = n_chunks > 1 || (h_text != nullptr && !(n_chunks == 1 && n_bytes <= SMALL_JOB_BYTES));
     if (fork) {
         if (!b->ev_fork) {
@@ -498,7 +515,6 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         HIP_TRY(hipEventRecord(b->ev_fork, s));
     }
     for (ChunkSet& cs : b->set) cs.used = false;
-
     if ((rc = ensure_pinned((void**)&b->h_info, &b->h_info_cap, ((size_t)n_chunks + 1) * 16, 0))) return rc;
     // tokens of chunk c to the host: on the copy stream, after the chunk's last kernel; the host needs the chunk's token
     // range for that (written to pinned memory by its scan), so this is called one chunk behind the enqueueing
@@ -543,6 +559,8 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
         w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
         w.inline_scan = (!fork && n_chunks == 1 && w.n_tiles >= 1 && w.n_tiles <= 1024) ? 1u : 0u;
+        w.memo = d_memo;
+        w.memo_mask = MEMO_SLOTS - 1;
 
         if (fork && !cs.used) { HIP_TRY(hipStreamWaitEvent(cst, b->ev_fork, 0)); cs.used = true; }
         if (h_text && b1 > b0) {
@@ -590,7 +608,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         if (fork) HIP_TRY(hipEventRecord(cs.ev_scan, cst));
         end();
         begin();
-        jtk_launch_strip_gather(w, cst);
+        jtk_launch_strip_expand(w, cst);
         end();
         begin();
         jtk_launch_doc_offsets(w, cst);

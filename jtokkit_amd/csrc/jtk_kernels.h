@@ -88,19 +88,24 @@ struct JtkWork {
     int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
     int64_t n_tiles;        // strips
     uint32_t count_only;    // countTokens(): the offsets are computed but no token ids are written
-    uint32_t inline_scan;   // small single-chunk job: the gather kernel adds up the strips before its own itself (no k_tile_scan)
+    uint32_t inline_scan;   // small single-chunk job: the expand kernel adds up the strips before its own itself (no k_tile_scan)
     uint32_t check_special; // encode(): flag documents that contain a special-token literal (done inside pretok_split)
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)
     uint64_t* gapmask;      // NULL, or (caller-supplied pieces, jtk_batch_encode_pieces) bit p: the "piece" that starts at byte p is
                             // text between two matches of the caller's pattern: it is not encoded (matcher.find() skips it)
-    uint32_t* stok;         // [n_tiles * JTK_TILE] the tokens of each strip, packed from the strip's first word (a strip of 4096
-                            // bytes has at most 4096 tokens); k_strip_gather moves them to their place in `tokens`
+    uint32_t* stok;         // [n_tiles * JTK_TILE] the tokens of each strip's DENSE pieces (<= 8 bytes, found in their primary tok8
+                            // slot), in order, packed from the strip's first word
+    uint64_t* holebits;     // [n_tiles * 64] per strip and chunk of 64 pieces: bit j: piece j of the chunk is a hole (anything else)
+    uint64_t* hrec;         // [n_tiles * JTK_TILE] per strip, by hole number: the hole's tokens (HR_* in jtk_strip_encode.h)
+    uint32_t* tile_np;      // [n_tiles] pieces of the strip
+    uint4* memo;            // NULL, or [8 XCDs][memo_mask + 1][2]: merged pieces remembered for the rest of the job (jtk_strip_encode.h)
+    uint32_t memo_mask;
     uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a long piece (> JTK_SHORT_MAX bytes), packed from the piece's first
                             // byte position (k <= len words); word 0 also carries the count k: id | k << 17
                             // (JTK_HT_ESCAPE: the count is in docpre[pos + 1])
     uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its strip before it (sparse)
-    uint32_t* tile_tot;     // [n_tiles] tokens of the strip
+    uint32_t* tile_tot;     // [n_tiles] tokens of the strip (zeroed per job; k_strip_encode adds to it)
     int64_t* tile_off;      // [n_tiles + 1] exclusive scan of tile_tot
     uint64_t* qm[JTK_NBINS];        // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k: position and length
     int64_t q_cap[JTK_NBINS];       // entries per shard
@@ -167,9 +172,9 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
 void jtk_launch_find_long(const JtkWork& w, hipStream_t s);                                   // pieces of > JTK_SHORT_MAX bytes -> queues
 void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);     // only if t.longtok.n
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);         // ... merged, tokens in htok
-void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // every strip's tokens -> stok
+void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // every strip: dense tokens, hole bitmap, hole records
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
-void jtk_launch_strip_gather(const JtkWork& w, hipStream_t s);                                // stok -> tokens
+void jtk_launch_strip_expand(const JtkWork& w, hipStream_t s);                                // ... -> tokens, docpre
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s);
 
 #endif

@@ -594,8 +594,8 @@ void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStre
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((w.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK)), dim3(1024), 0, s, w);
 }
-void jtk_launch_strip_gather(const JtkWork& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_strip_gather, dim3((unsigned)((w.n_tiles + GATHER_THREADS / 64 - 1) / (GATHER_THREADS / 64))), dim3(GATHER_THREADS), 0, s, w);
+void jtk_launch_strip_expand(const JtkWork& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_strip_expand, dim3((unsigned)((w.n_tiles + EXPAND_THREADS / 64 - 1) / (EXPAND_THREADS / 64))), dim3(EXPAND_THREADS), 0, s, w);
 }
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s) {
     const int64_t n = w.n_docs + 1;

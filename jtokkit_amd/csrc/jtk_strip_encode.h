@@ -1,56 +1,71 @@
-// jtk_strip_encode.h -- k_strip_encode: from the piece mask of a strip of text to its tokens in ONE pass, and
-// k_strip_gather, which moves every strip's tokens to their place in the batch's packed output.  Included by
+// jtk_strip_encode.h -- k_strip_encode: from the piece mask of a strip of text to its tokens without a piece list, a
+// queue or a merge result ever leaving the wave, and k_strip_expand, which writes the packed token stream.  Included by
 // jtk_kernels.hip inside its anonymous namespace.
 //
 // This is the loop of encodeOrdinaryInternal (GptBytePairEncoding.java:77-87) -- for every piece: the whole-piece lookup
-// (:81-83), else bytePairMerge (:84-86, :200-275), tokens appended in text order -- with nothing written in between: the
-// piece list, the pieces that need merging and their results never leave the wave.
+// (:81-83), else bytePairMerge (:84-86, :200-275), tokens appended in text order.
 //
-// ONE WAVE PER STRIP of 4096 bytes = 64 piece-mask words, one per lane.  The wave is a small pipeline over the strip's
-// pieces, 64 at a time ("chunks"):
-//   resolve  lane j of chunk c takes piece 64 c + j: up to 16 bytes straight from the text (one unaligned 16-byte load: the
-//            strip is in L1/L2, neighbouring lanes read overlapping bytes), one probe of the whole-piece tables (tok8 / tok16,
-//            primary-first: one scattered fetch; a second round only for lanes that miss in a flagged slot).  The answer is
-//            ONE word per piece, kept in a register ring indexed by the chunk (ring[c % 16], lane j): token id, or "hard"
-//            (no table entry: its place in the pending list), or "long" (> 16 bytes: merged earlier, tokens in htok), or
-//            "gap" (custom patterns: unmatched text).
-//   merge    when 64 hard pieces are pending (or nothing is left to resolve) one lane per pending piece runs bytePairMerge
-//            (jtk_lean_merge.h) with its parts in the wave's LDS; the results stay there.
-//   pack     all pieces before the first one that is still pending: token counts (1, or the merged piece's), a wave prefix
-//            sum, tokens stored at the strip's place in `stok` (dense from the strip's first word) and, for a piece that
-//            starts a document, the tokens of the strip before it (docpre).
-// The waves of a workgroup share only the read-only tables in LDS (2-byte-token ranks, byte -> id): no barrier after the
-// prologue.  A workgroup keeps its CU for the whole launch; its waves take strips round robin.
-// What leaves the wave per strip: the tokens (4 bytes each, to stok), one count (tile_tot), docpre for document starts.
+// ONE WAVE PER STRIP of 4096 bytes = 64 piece-mask words, one per lane; a wave takes strips round robin for the whole
+// launch.  Work is split by how often it is needed, so that the common case costs few instructions and the rare cases run
+// 64 lanes wide:
+//   main path   lane j of chunk c takes piece 64 c + j.  A piece of <= 8 bytes probes its PRIMARY slot of the tok8 table
+//               (one unaligned 8-byte load of the text, one 16-byte fetch of the slot).  A hit is a "dense" piece: its token
+//               goes straight to the strip's dense token block (stok), in order.  Everything else -- a piece of more than
+//               8 bytes, an entry displaced to its secondary slot, a piece that is no entry -- is a HOLE: a bit in the
+//               strip's hole bitmap and an entry (strip, hole number, offset, length) in the wave's pending ring in LDS.
+//   hole batch  when 64 holes are pending, one lane per hole: the complete whole-piece lookup (tok8 / tok16, primary and
+//               secondary slot), pieces of more than 16 bytes (merged earlier by k_bpe_merge: count from htok), unmatched
+//               text of custom patterns, and pieces of 2..3 bytes that are no entry (at most one merge, from the LDS tables).
+//               Each result is an 8-byte hole record (hrec); a piece that needs bytePairMerge moves on to the hard ring.
+//   merge round when 64 hard pieces are pending, one lane per piece runs bytePairMerge (jtk_lean_merge.h) with its parts
+//               in the wave's LDS; the result is the piece's hole record (more than three tokens: in htok).
+// The rings live across strips, so batches and rounds are full except for the last ones of a wave.  Holes do not hold up
+// the dense tokens: k_strip_expand merges both streams.
+// What leaves the wave per strip: dense tokens (4 B each), the hole bitmap (512 B), hole records (8 B each), the piece
+// count; token counts are added to tile_tot.
 #ifndef JTK_ENC_WAVES
 #define JTK_ENC_WAVES 12
 #endif
 constexpr int ENC_WAVES = JTK_ENC_WAVES, ENC_THREADS = 64 * ENC_WAVES;
-constexpr int ENC_RING = 16;                   // chunks whose answers wait in registers
-constexpr int ENC_WIN = 1024;                  // piece starts listed in LDS at a time
-#ifndef JTK_ENC_G
-#define JTK_ENC_G 2
-#endif
-constexpr int ENC_G = JTK_ENC_G;               // chunks resolved per step (loads in flight per lane)
-constexpr int ENC_PEND = 256;                  // pending hard pieces (a ring: at most 63 + 64 ENC_G wait)
-static_assert(63 + 64 * ENC_G < ENC_PEND && ENC_WIN % (64 * ENC_G) == 0, "pending ring / window");
+constexpr int ENC_WIN = 512;                   // piece starts listed in LDS at a time
+constexpr int ENC_PEND = 128;                  // ring of pending holes / hard pieces (at most 127 wait)
 static_assert(T == 4096, "a strip is 64 mask words: one per lane");
 
-// ring word of a piece
-constexpr uint32_t RW_S_MASK = 0xFFFu;         // bits 0..11: byte offset of the piece in the strip
-constexpr uint32_t RW_DOC = 1u << 12;          // a document starts with this piece
-constexpr int RW_KIND_SHIFT = 13;              // bits 13..14
-constexpr uint32_t RW_TOKEN = 0u, RW_HARD = 1u, RW_LONG = 2u, RW_GAP = 3u;
-constexpr int RW_PAY_SHIFT = 15;               // bits 15..31: token id, or the piece's index in the pending ring
+// hole record (8 bytes)
+constexpr int HR_KIND_SHIFT = 53;              // bits 53..54
+constexpr uint64_t HR_TOKS = 0;                // bits 0..50: up to three token ids, 17 bits each; bits 51..52: count - 1
+constexpr uint64_t HR_REF = 1;                 // bits 0..20: count; bits 21..32: offset of the piece in the strip: tokens in htok
+constexpr uint64_t HR_GAP = 2;                 // no tokens
+
+// Memo of merged pieces (per XCD, insert-only, cleared per job): a piece of 4..16 bytes that bytePairMerge turned into at most
+// six tokens is remembered under its bytes, so that its next occurrence -- natural text repeats its words -- costs one
+// lookup in the hole batch instead of a merge.  An entry is 32 bytes: the piece's 16 key bytes | lo64 | hi64 with
+//   lo64 = tokens 0..2 (17 bits each) | tag13 << 51;   hi64 = tokens 3..5 | count << 51 | len << 54 | tag5 << 59.
+// Only the wave that claims an empty slot (compare-and-swap of hi64 from 0 to MEMO_BUSY) ever writes it, and never again, so
+// each of the entry's words is either still zero or final: a reader that finds its key, its length and both tags (nonzero,
+// taken from the key's hash) has read a complete entry of exactly its key; anything else is a miss, and a miss only costs the
+// merge.  Each XCD has its own table: its L2 is the point of coherence for all its CUs, and nothing crosses XCDs.
+constexpr uint64_t MEMO_BUSY = 1ull << 51;
+constexpr uint32_t MEMO_MAX_TOKENS = 6;
+
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7u;
+}
+__device__ __forceinline__ uint32_t memo_slot(uint32_t mix, uint32_t mask) { return (jtk_pair_mix2(mix) ^ (mix >> 9)) & mask; }
+__device__ __forceinline__ uint32_t memo_tag(uint32_t mix) { return ((mix >> 17) & 0x1FFFu) | 1u; }
 
 struct __attribute__((aligned(16))) EncWaveLds {
     uint32_t id[16 * 64];                      // parts of the pieces being merged: token ids, [slot][lane] ...
-    uint32_t rk[16 * 64];                      // ... and pair keys; after a round rk[lane] = the lane's live-part mask
-    uint32_t pend[ENC_PEND];                   // pending hard pieces: piece index (12) | offset << 12 | (len - 1) << 24
-    uint16_t starts[ENC_WIN + 8];             // byte offsets of pieces k0 .. k0 + ENC_WIN (one more: where the last ends)
+    uint32_t rk[16 * 64];                      // ... and pair keys
+    uint2 holes[ENC_PEND];                     // pending holes:  x = offset (12) | (min(len, 17) - 1) << 12 | hole number << 17, y = strip
+    uint2 hard[ENC_PEND];                      // pending pieces for bytePairMerge: the same
+    uint16_t starts[ENC_WIN + 8];              // byte offsets of pieces k0 .. k0 + ENC_WIN (one more: where the last ends)
 };
 
 struct __attribute__((packed, aligned(1))) U4Bytes { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U2Bytes { uint32_t x, y; };
 
 // the 16 bytes at text position p (bytes at or beyond n read as zero); p + 16 <= n is the fast path
 __device__ __forceinline__ uint4 load_text16(const uint8_t* text, int64_t p, int64_t n) {
@@ -75,6 +90,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 }
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) { return mbcnt64_(m); }
+
+// Token counts of a batch of lanes to tile_tot: the lanes' strips come in runs (ring order is text order), so the first
+// lane of each run adds the run's sum.  All lanes call this; lanes without a piece pass have = false.
+__device__ __forceinline__ void add_strip_counts(const JtkWork& w, uint32_t strip, bool have, uint32_t cc) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t key = have ? strip : 0xFFFFFFFFu;
+    const uint32_t c = have ? cc : 0u;
+    const uint32_t inc = wave_incl_scan_dpp(c);
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool head = lane == 0 || prev != key;
+    const uint64_t heads = __ballot(head);
+    const uint64_t later = heads & ~((2ull << lane) - 1ull);                  // run heads after this lane
+    const int last = later ? jtk_ctz64(later) - 1 : 63;                        // last lane of this lane's run
+    const uint32_t run_end = (uint32_t)__shfl((int)inc, last);
+    if (head && have) {
+        const uint32_t sum = run_end - (inc - c);
+        if (sum) atomicAdd(&w.tile_tot[strip], sum);
+    }
+}
 
 #ifdef JTK_ENC_STAMP
 // diagnostic build: wave cycles per phase, summed over the launch (never read by the kernels; jtk_debug_stamps() fetches them)
@@ -104,35 +138,219 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
     EncWaveLds& W = s_wave[wv];
     uint32_t* const id = W.id + lane;
     uint32_t* const rk = W.rk + lane;
-    const LeanLds LL{W.id, W.rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
+    const JtkBpLds bp{s_bpbits, s_bpcum, s_bpranks};
+    const LeanLds LL{W.id, W.rk, bp, s_brank};
     const int64_t n = w.n_bytes;
     const bool gaps = w.gapmask != nullptr;
-    const bool store = w.count_only == 0;
     const uint8_t* const tok = reinterpret_cast<const uint8_t*>(t.tok8.slots);   // the tok8 slots, then the tok16 slots: one allocation
     const uint32_t rel16 = (uint32_t)(reinterpret_cast<const uint8_t*>(t.tok16.slots) - tok);
+    const uint32_t n8 = t.tok8.bits, n16 = t.tok16.n;
 #ifdef JTK_ENC_STAMP
     uint64_t st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t st_wave0 = __builtin_amdgcn_s_memtime();
 #endif
+    uint4* const memo = w.memo ? w.memo + (size_t)xcc_id() * ((size_t)w.memo_mask + 1u) * 2u : nullptr;   // this XCD's table
+    uint32_t ho_head = 0, ho_tail = 0;            // pending holes  [head, tail)   (wave-uniform)
+    uint32_t hd_head = 0, hd_tail = 0;            // pending hard pieces
+
+    // ---- one merge round: a lane per pending hard piece (GptBytePairEncoding.java:200-275)
+    auto merge_round = [&](uint32_t nl) {
+        STAMP_BEGIN();
+        STAMP_ADD(5, 1);
+        STAMP_ADD(6, nl);
+        wave_lds_fence();
+        const bool mine = (uint32_t)lane < nl;
+        const uint2 pe = W.hard[(hd_head + (uint32_t)lane) & (ENC_PEND - 1)];
+        const uint32_t strip = pe.y, s = pe.x & 0xFFFu, h = pe.x >> 17;
+        const int len = mine ? (int)((pe.x >> 12) & 31u) + 1 : 0;
+        const int64_t pos = mine ? (int64_t)strip * T + s : 0;
+        const uint4 tx = load_text16(w.text, pos, n);
+        const uint32_t d4[4] = {tx.x, tx.y, tx.z, tx.w};
+        uint32_t b[17];
+#pragma unroll
+        for (int j = 0; j < 16; j++) b[j] = (d4[j >> 2] >> (8 * (j & 3))) & 255u;
+        b[16] = 0;
+        uint32_t alive;
+        // the round's longest piece picks the unrolled variant: 8, 12 or 16 slots
+        if (!__ballot(len > 8)) { uint32_t c[9]; for (int j = 0; j < 9; j++) c[j] = b[j]; alive = lean_piece16<8, 64>(LL, id, rk, c, len, t); }
+        else if (!__ballot(len > 12)) { uint32_t c[13]; for (int j = 0; j < 13; j++) c[j] = b[j]; alive = lean_piece16<12, 64>(LL, id, rk, c, len, t); }
+        else alive = lean_piece16<16, 64>(LL, id, rk, b, len, t);
+        // emit (:270-273): the hole record; more than three tokens go to htok, packed from the piece's first byte position
+        const uint32_t c = (uint32_t)__popc(alive);
+        if (mine) {
+            uint64_t rec;
+            if (c <= 3u) {
+                uint32_t a = alive;
+                uint32_t tk[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { const uint32_t j = a ? (uint32_t)__builtin_ctz(a) : 0u; tk[i] = a ? id[j * 64] : 0u; a &= a - 1u; }
+                rec = (uint64_t)tk[0] | ((uint64_t)tk[1] << 17) | ((uint64_t)tk[2] << 34) | ((uint64_t)(c - 1u) << 51) | (HR_TOKS << HR_KIND_SHIFT);
+            } else {
+                uint32_t* dst = w.htok + pos;
+                uint32_t i = 0;
+                for (uint32_t a = alive; a; a &= a - 1u) dst[i++] = id[(uint32_t)__builtin_ctz(a) * 64];
+                rec = (uint64_t)c | ((uint64_t)s << 21) | (HR_REF << HR_KIND_SHIFT);
+            }
+            w.hrec[(int64_t)strip * T + h] = rec;
+        }
+        if (memo) {
+            // remember the result under the piece's bytes (only the lane that claims an empty slot writes it)
+            const uint32_t ulen = (uint32_t)len;
+            const uint64_t runm = ~0ull >> ((0u - 8u * ulen) & 63u);
+            const bool big = ulen > 8u;
+            const uint64_t mlo = big ? ~0ull : runm, mhi = big ? runm : 0ull;
+            const uint32_t key0 = tx.x & (uint32_t)mlo, key1 = tx.y & (uint32_t)(mlo >> 32), key2 = tx.z & (uint32_t)mhi, key3 = tx.w & (uint32_t)(mhi >> 32);
+            if (mine && c <= MEMO_MAX_TOKENS && key0 != 0u) {
+                const uint32_t mix = jtk_tok16_mix(key0, key1, key2, key3, ulen);
+                uint4* e = memo + (size_t)memo_slot(mix, w.memo_mask) * 2u;
+                unsigned long long* hi64 = reinterpret_cast<unsigned long long*>(e + 1) + 1;
+                if (atomicCAS(hi64, 0ull, (unsigned long long)MEMO_BUSY) == 0ull) {
+                    uint32_t a = alive;
+                    uint64_t tk[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { const uint32_t j = a ? (uint32_t)__builtin_ctz(a) : 0u; tk[i] = a ? id[j * 64] : 0u; a &= a - 1u; }
+                    const uint32_t tag = memo_tag(mix);
+                    e[0] = make_uint4(key0, key1, key2, key3);
+                    reinterpret_cast<unsigned long long*>(e + 1)[0] = tk[0] | (tk[1] << 17) | (tk[2] << 34) | ((uint64_t)tag << 51);
+                    *hi64 = tk[3] | (tk[4] << 17) | (tk[5] << 34) | ((uint64_t)c << 51) | ((uint64_t)ulen << 54) | ((uint64_t)(tag & 31u) << 59);
+                }
+            }
+        }
+        add_strip_counts(w, strip, mine, c);
+        wave_lds_fence();
+        hd_head += nl;
+        STAMP_END(2);
+    };
+
+    // ---- one hole batch: a lane per pending hole -- everything the main path does not do
+    auto hole_batch = [&](uint32_t nl) {
+        STAMP_BEGIN();
+        STAMP_ADD(10, 1);
+        STAMP_ADD(11, nl);
+        wave_lds_fence();
+        const bool mine = (uint32_t)lane < nl;
+        const uint2 pe = W.holes[(ho_head + (uint32_t)lane) & (ENC_PEND - 1)];
+        const uint32_t strip = pe.y, s = pe.x & 0xFFFu, h = pe.x >> 17;
+        const uint32_t lenc = mine ? ((pe.x >> 12) & 31u) + 1u : 0u;             // 17: more than 16 bytes
+        const int64_t pos = mine ? (int64_t)strip * T + s : 0;
+        const bool shortp = lenc <= (uint32_t)JTK_SHORT_MAX;
+        const uint32_t len = shortp ? lenc : 0u;
+        // the whole-piece lookup (:81-83), complete: tok8 or tok16, primary slot, then the secondary one where the primary says so
+        const uint4 tx = load_text16(w.text, pos, n);
+        const uint64_t runm = ~0ull >> ((0u - 8u * len) & 63u);                  // 8 len ones (len 8 and 16: all 64)
+        const bool big = len > 8u;
+        const uint64_t mlo = big ? ~0ull : runm, mhi = big ? runm : 0ull;
+        const uint32_t key0 = tx.x & (uint32_t)mlo, key1 = tx.y & (uint32_t)(mlo >> 32);
+        const uint32_t key2 = tx.z & (uint32_t)mhi, key3 = tx.w & (uint32_t)(mhi >> 32);
+        const uint32_t mix = jtk_tok16_mix(key0, key1, key2, key3, len);
+        uint4 ka;
+        uint2 ma = make_uint2(0, 0);
+        auto fetch = [&](uint32_t mx) {
+            const uint32_t hh = jtk_reduce32(mx, big ? n16 : n8);
+            const uint8_t* sa = tok + (big ? (hh << 5) + rel16 : (hh << 4));
+            ka = *reinterpret_cast<const uint4*>(sa);                            // tok8: lo, hi, id, len; tok16: the 16 key bytes
+            if (big) ma = *reinterpret_cast<const uint2*>(sa + 16);              // tok16: id, len
+        };
+        auto check = [&](uint32_t& idv, bool& more) {
+            const uint32_t slen = big ? ma.y : ka.w;
+            const uint32_t diff = (ka.x ^ key0) | (ka.y ^ key1) | ((slen & JTK_TOK_LEN_MASK) ^ len) | (big ? ((ka.z ^ key2) | (ka.w ^ key3)) : 0u);
+            idv = diff == 0u ? (big ? ma.x : ka.z) : JTK_RANK_NONE;
+            more = diff != 0u && (slen & JTK_TOK_FILTER_BIT(mix)) != 0u && len != 0u;
+        };
+        uint32_t tokid;
+        bool more;
+        fetch(mix);
+        check(tokid, more);
+        if (__ballot(more)) {
+            if (more) { bool dummy; fetch(jtk_pair_mix2(mix)); check(tokid, dummy); }
+        }
+        bool gap = false;
+        if (gaps) gap = mine && ((w.gapmask[pos >> 6] >> (pos & 63)) & 1ull);
+        const bool hit = mine && shortp && tokid != JTK_RANK_NONE && !gap;
+        const bool islong = mine && !shortp && !gap;
+        uint64_t rec = (uint64_t)tokid | (HR_TOKS << HR_KIND_SHIFT);            // one token
+        uint32_t cnt = hit ? 1u : 0u;
+        if (gap) rec = HR_GAP << HR_KIND_SHIFT;
+        if (__ballot(islong)) {
+            if (islong) {
+                // merged by k_bpe_merge: the count is in the header word (giant pieces: docpre[pos + 1])
+                cnt = (w.htok[pos] >> JTK_HT_CNT_SHIFT) & JTK_HT_CNT_MASK;
+                if (cnt == JTK_HT_ESCAPE) cnt = w.docpre[pos + 1];
+                rec = (uint64_t)cnt | ((uint64_t)s << 21) | (HR_REF << HR_KIND_SHIFT);
+            }
+        }
+        bool hard = mine && shortp && !hit && !gap;
+        // pieces of 2 or 3 bytes that are no entry: bytePairMerge makes no lookup that can hit beyond the 2-byte-token ranks of
+        // their byte pairs: merge the pair of lower rank, the left one on a tie (:236), if either is a token
+        const bool tiny = hard && len <= 3u;
+        if (__ballot(tiny)) {
+            if (tiny) {
+                const uint32_t b0 = key0 & 255u, b1 = (key0 >> 8) & 255u, b2 = (key0 >> 16) & 255u;
+                const bool three = len == 3u;
+                const uint32_t r01 = three ? jtk_bp_lookup(bp, (b0 << 8) | b1) : JTK_RANK_NONE;
+                const uint32_t r12 = three ? jtk_bp_lookup(bp, (b1 << 8) | b2) : JTK_RANK_NONE;
+                const uint32_t i0 = s_brank[b0], i1 = s_brank[b1], i2 = s_brank[b2];
+                uint32_t t0 = i0, t1 = i1, t2 = i2;
+                cnt = three ? 3u : 2u;
+                if (r01 != JTK_RANK_NONE && r01 <= r12) { t0 = r01; t1 = i2; cnt = 2u; }
+                else if (r12 != JTK_RANK_NONE) { t1 = r12; cnt = 2u; }
+                if (cnt == 2u) t2 = 0u;
+                rec = (uint64_t)t0 | ((uint64_t)t1 << 17) | ((uint64_t)t2 << 34) | ((uint64_t)(cnt - 1u) << 51) | (HR_TOKS << HR_KIND_SHIFT);
+            }
+            hard = hard && !tiny;
+        }
+        // a piece this XCD has merged before: its tokens from the memo
+        if (memo && __ballot(hard)) {
+            const bool cand = hard && key0 != 0u;
+            const uint4* e = memo + (size_t)(cand ? memo_slot(mix, w.memo_mask) : 0u) * 2u;
+            const uint4 h0 = e[0], h1 = e[1];
+            const uint32_t tag = memo_tag(mix);
+            const bool ok = cand && ((h0.x ^ key0) | (h0.y ^ key1) | (h0.z ^ key2) | (h0.w ^ key3)) == 0u && (h1.y >> 19) == tag &&
+                            (h1.w >> 27) == (tag & 31u) && ((h1.w >> 22) & 31u) == len;
+            if (__ballot(ok)) {
+                if (ok) {
+                    const uint64_t lo = ((uint64_t)h1.y << 32) | h1.x, hi = ((uint64_t)h1.w << 32) | h1.z;
+                    cnt = (uint32_t)(hi >> 51) & 7u;
+                    if (cnt <= 3u) rec = (lo & ((1ull << 51) - 1ull)) | ((uint64_t)(cnt - 1u) << 51) | (HR_TOKS << HR_KIND_SHIFT);
+                    else {
+                        uint32_t* dst = w.htok + pos;
+                        dst[0] = (uint32_t)lo & JTK_HT_ID_MASK; dst[1] = (uint32_t)(lo >> 17) & JTK_HT_ID_MASK; dst[2] = (uint32_t)(lo >> 34) & JTK_HT_ID_MASK;
+                        dst[3] = (uint32_t)hi & JTK_HT_ID_MASK;
+                        if (cnt > 4u) dst[4] = (uint32_t)(hi >> 17) & JTK_HT_ID_MASK;
+                        if (cnt > 5u) dst[5] = (uint32_t)(hi >> 34) & JTK_HT_ID_MASK;
+                        rec = (uint64_t)cnt | ((uint64_t)s << 21) | (HR_REF << HR_KIND_SHIFT);
+                    }
+                }
+                hard = hard && !ok;
+                STAMP_ADD(13, __popcll(__ballot(ok)));
+            }
+        }
+        if (mine && !hard) w.hrec[(int64_t)strip * T + h] = rec;
+        add_strip_counts(w, strip, mine && !hard, cnt);
+        // the rest needs bytePairMerge: on to the hard ring (text order is kept)
+        const uint64_t hb = __ballot(hard);
+        if (hard) W.hard[(hd_tail + mbcnt64(hb)) & (ENC_PEND - 1)] = pe;
+        hd_tail += (uint32_t)__popcll(hb);
+        ho_head += nl;
+        wave_lds_fence();
+        STAMP_END(3);
+    };
 
     for (int64_t strip = (int64_t)wv * gridDim.x + blockIdx.x; strip < w.n_tiles; strip += (int64_t)gridDim.x * ENC_WAVES) {
         const int64_t B = strip * T;
         const int64_t wd = (B >> 6) + lane;
-        // this lane's mask words: piece starts (without the end sentinel), unmatched text, document starts
+        // this lane's mask word: piece starts (without the end sentinel)
         uint64_t pm = piece_word(w, wd);
         if (wd * 64 + 63 >= n) pm &= (wd * 64 >= n) ? 0ull : ((1ull << (n - wd * 64)) - 1ull);
-        const uint64_t gm = (gaps && wd < w.n_words) ? w.gapmask[wd] : 0ull;
-        const uint64_t dm = (wd < w.n_words) ? w.docmask[wd] : 0ull;
+        const uint64_t gm = (gaps && wd < w.n_words) ? w.gapmask[wd] : 0ull;    // custom patterns: text no match covers
         // (touch the strip's text -- one word of every 64-byte block -- so that it is on its way while the masks are scanned)
         const uint32_t touch = (B + lane * 64 < n) ? *reinterpret_cast<const uint32_t*>(w.text + B + lane * 64) : 0u;
         const uint32_t cnt = (uint32_t)__popcll(pm);
         const uint32_t inc = wave_incl_scan_dpp(cnt);
         const int np = (int)(uint32_t)__shfl((int)inc, 63);
         const uint32_t pre = inc - cnt;
-        if (np == 0) {                                                   // a strip inside one long piece
-            if (lane == 0) w.tile_tot[strip] = 0;
-            continue;
-        }
+        if (lane == 0) w.tile_np[strip] = (uint32_t)np;
+        if (np == 0) continue;                                           // a strip inside one long piece
         // where the strip's last piece ends, relative to B: the end sentinel or the next strip's first piece (only "more
         // than 16 bytes away" matters beyond that: such a piece was merged by k_bpe_merge, its length is not needed here)
         uint32_t end_rel;
@@ -145,230 +363,89 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
             end_rel = some ? (uint32_t)(T + first * 64 + jtk_ctz64(fw)) : (uint32_t)(2 * T);
             if (n - B < T) end_rel = (uint32_t)(n - B);                      // the sentinel is inside this strip
         }
-
-        // ---- the wave's state: all wave-uniform
-        int k0 = -ENC_WIN;                        // first piece of the listed window
-        int k_res = 0;                            // pieces resolved (a multiple of 64 until the end)
-        int k_pack = 0;                           // pieces packed
-        uint32_t pn_head = 0, pn_tail = 0;        // pending ring: [head, tail) wait for a merge round
-        uint32_t round_base = 0;                  // the pending index that lane 0 of the last merge round took
-        uint32_t run = 0;                         // tokens of the strip so far
-        uint32_t ring[ENC_RING];
-#pragma unroll
-        for (int i = 0; i < ENC_RING; i++) ring[i] = 0;
         uint32_t* const out = w.stok + B;
+        uint32_t run = 0;                                                // dense tokens of the strip so far
+        uint32_t nholes = 0;
+        uint64_t hw = 0;                                                 // lane c: the hole mask of chunk c
+        const bool tail_strip = B + T + 16 > n;                          // (the last strips of the text: careful loads)
+        int k0 = -ENC_WIN;
 
-        while (k_pack < np) {
-            // ---- resolve chunks while the pending list is short of a full round and the ring has room: ENC_G chunks per
-            // step, so that a lane has ENC_G text loads and then ENC_G table probes in flight (what bounds this phase is the
-            // latency of those two dependent loads, not their number)
-            while (k_res < np && pn_tail - pn_head < 64u && (k_res >> 6) - (k_pack >> 6) < ENC_RING) {
-                STAMP_BEGIN();
-                if (k_res >= k0 + ENC_WIN) {
-                    // list the starts of pieces k0 .. k0 + ENC_WIN (each lane: the set bits of its word)
-                    k0 += ENC_WIN;
-                    wave_lds_fence();
-                    uint32_t i = pre;
-                    for (uint64_t m = pm; m; m &= m - 1, i++) {
-                        const int rel = (int)i - k0;
-                        if (rel >= 0 && rel <= ENC_WIN) W.starts[rel] = (uint16_t)(lane * 64 + jtk_ctz64(m));
-                    }
-                    if (lane == 0 && np - k0 <= ENC_WIN) W.starts[np - k0] = (uint16_t)end_rel;
-                    wave_lds_fence();
-                }
-                // chunks of this step: as many as the ring, the listed window and the strip allow
-                int g = ENC_RING - ((k_res >> 6) - (k_pack >> 6));
-                g = min(g, min((k0 + ENC_WIN - k_res) >> 6, (np - k_res + 63) >> 6));
-                g = min(g, ENC_G);
-                bool have[ENC_G], shortp[ENC_G], big[ENC_G];
-                uint32_t s[ENC_G], len[ENC_G], key0[ENC_G], key1[ENC_G], key2[ENC_G], key3[ENC_G], mix[ENC_G];
-                uint4 tx[ENC_G], ka[ENC_G];
-                uint2 ma[ENC_G];
-                // (chunks q >= g are computed too -- on piece 0, results dropped -- so that there is no branch between the loads)
-                bool tail = false;
-#pragma unroll
-                for (int q = 0; q < ENC_G; q++) {
-                    const int k = k_res + 64 * q + lane;
-                    have[q] = q < g && k < np;
-                    const int rel = have[q] ? k - k0 : 0;
-                    const uint32_t e = W.starts[rel + 1];
-                    s[q] = W.starts[rel];
-                    const uint32_t plen = have[q] ? e - s[q] : 0u;                   // (> 16: only "long" matters)
-                    shortp[q] = plen <= (uint32_t)JTK_SHORT_MAX;
-                    len[q] = shortp[q] ? plen : 0u;
-                    tail = tail || B + s[q] + 16 > n;
-                }
-                // up to 16 bytes of every piece: one unaligned load each, back to back (only the last bytes of the text need care)
-                if (!__ballot(tail)) {
-#pragma unroll
-                    for (int q = 0; q < ENC_G; q++) {
-                        const U4Bytes v = *reinterpret_cast<const U4Bytes*>(w.text + B + s[q]);
-                        tx[q] = make_uint4(v.x, v.y, v.z, v.w);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < ENC_G; q++) tx[q] = load_text16(w.text, B + s[q], n);
-                }
-                auto slot_off = [&](int q, uint32_t mx) -> uint32_t {
-                    const uint32_t h = jtk_reduce32(mx, big[q] ? t.tok16.n : t.tok8.bits);
-                    return big[q] ? (h << 5) + rel16 : (h << 4);
-                };
-#pragma unroll
-                for (int q = 0; q < ENC_G; q++) {
-                    const uint64_t runm = ~0ull >> ((0u - 8u * len[q]) & 63u);       // 8 len ones (len 8 and 16: all 64)
-                    big[q] = len[q] > 8u;
-                    const uint64_t mlo = big[q] ? ~0ull : runm, mhi = big[q] ? runm : 0ull;
-                    key0[q] = tx[q].x & (uint32_t)mlo; key1[q] = tx[q].y & (uint32_t)(mlo >> 32);
-                    key2[q] = tx[q].z & (uint32_t)mhi; key3[q] = tx[q].w & (uint32_t)(mhi >> 32);
-                    // one mix for both tables and both choices; only base, slot size and slot count depend on the length
-                    mix[q] = jtk_tok16_mix(key0[q], key1[q], key2[q], key3[q], len[q]);
-                    const uint8_t* sa = tok + slot_off(q, mix[q]);
-                    ka[q] = *reinterpret_cast<const uint4*>(sa);                     // tok8: lo, hi, id, len; tok16: the 16 key bytes
-                    ma[q] = make_uint2(0, 0);
-                    if (big[q]) ma[q] = *reinterpret_cast<const uint2*>(sa + 16);    // tok16: id, len
-                }
-                auto check = [&](int q, uint32_t& idv, bool& more) {
-                    const uint32_t slen = big[q] ? ma[q].y : ka[q].w;
-                    const uint32_t diff = (ka[q].x ^ key0[q]) | (ka[q].y ^ key1[q]) | ((slen & JTK_TOK_LEN_MASK) ^ len[q]) |
-                                          (big[q] ? ((ka[q].z ^ key2[q]) | (ka[q].w ^ key3[q])) : 0u);
-                    idv = diff == 0u ? (big[q] ? ma[q].x : ka[q].z) : JTK_RANK_NONE;
-                    // (the slot's filter says whether a key with this mix can be among those it turned away)
-                    more = diff != 0u && (slen & JTK_TOK_FILTER_BIT(mix[q])) != 0u && len[q] != 0u;
-                };
-                uint32_t tokid[ENC_G];
-                bool more[ENC_G], any_more = false;
-#pragma unroll
-                for (int q = 0; q < ENC_G; q++) { check(q, tokid[q], more[q]); any_more = any_more || more[q]; }
-                if (__ballot(any_more)) {                                            // secondary slots, for the lanes that need them
-#pragma unroll
-                    for (int q = 0; q < ENC_G; q++) {
-                        if (more[q]) {
-                            const uint8_t* sa = tok + slot_off(q, jtk_pair_mix2(mix[q]));
-                            ka[q] = *reinterpret_cast<const uint4*>(sa);
-                            if (big[q]) ma[q] = *reinterpret_cast<const uint2*>(sa + 16);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < ENC_G; q++) { bool dummy; if (more[q]) check(q, tokid[q], dummy); }
-                }
-#pragma unroll
-                for (int q = 0; q < ENC_G; q++) {
-                    bool gap = false;
-                    if (gaps) {                                                      // (wave-uniform; the shuffles are evaluated by all lanes)
-                        const uint32_t glo = (uint32_t)__shfl((int)(uint32_t)gm, (int)(s[q] >> 6)), ghi = (uint32_t)__shfl((int)(uint32_t)(gm >> 32), (int)(s[q] >> 6));
-                        gap = have[q] && (((s[q] & 32u) ? ghi : glo) >> (s[q] & 31u)) & 1u;
-                    }
-                    const uint32_t dlo = (uint32_t)__shfl((int)(uint32_t)dm, (int)(s[q] >> 6)), dhi = (uint32_t)__shfl((int)(uint32_t)(dm >> 32), (int)(s[q] >> 6));
-                    const bool isdoc = have[q] && (((s[q] & 32u) ? dhi : dlo) >> (s[q] & 31u)) & 1u;
-                    const bool hit = have[q] && shortp[q] && tokid[q] != JTK_RANK_NONE && !gap;
-                    const bool hard = have[q] && shortp[q] && !hit && !gap;
-                    const uint64_t hb = __ballot(hard);
-                    const uint32_t pidx = pn_tail + mbcnt64(hb);
-                    if (hard) W.pend[pidx & (ENC_PEND - 1)] = (uint32_t)(k_res + 64 * q + lane) | (s[q] << 12) | ((len[q] - 1u) << 24);
-                    pn_tail += (uint32_t)__popcll(hb);
-                    const uint32_t kind = gap ? RW_GAP : hit ? RW_TOKEN : hard ? RW_HARD : RW_LONG;
-                    const uint32_t pay = hit ? tokid[q] : (pidx & (ENC_PEND - 1));
-                    if (q < g)
-                        ring[__builtin_amdgcn_readfirstlane(((k_res >> 6) + q) & (ENC_RING - 1))] = s[q] | (isdoc ? RW_DOC : 0u) | (kind << RW_KIND_SHIFT) | (pay << RW_PAY_SHIFT);
-                }
-                k_res += 64 * g;
-                STAMP_END(1);
-                STAMP_ADD(4, g);
-            }
-            // ---- one merge round: a lane per pending piece (GptBytePairEncoding.java:200-275)
-            const uint32_t nround = min(64u, pn_tail - pn_head);
-            if (nround) {
-                STAMP_BEGIN();
-                STAMP_ADD(5, 1);
-                STAMP_ADD(6, nround);
-                wave_lds_fence();                                                // the pending entries; the last round's results are consumed
-                const bool mine = (uint32_t)lane < nround;
-                const uint32_t pe = mine ? W.pend[(pn_head + (uint32_t)lane) & (ENC_PEND - 1)] : 0u;
-                const uint32_t s = (pe >> 12) & 0xFFFu;
-                const int len = mine ? (int)(pe >> 24) + 1 : 0;
-                const uint4 tx = load_text16(w.text, B + s, n);
-                const uint32_t d4[4] = {tx.x, tx.y, tx.z, tx.w};
-                uint32_t b[17];
-#pragma unroll
-                for (int j = 0; j < 16; j++) b[j] = (d4[j >> 2] >> (8 * (j & 3))) & 255u;
-                b[16] = 0;
-                uint32_t alive;
-                // the round's longest piece picks the unrolled variant: 8, 12 or 16 slots
-                if (!__ballot(len > 8)) { uint32_t c[9]; for (int j = 0; j < 9; j++) c[j] = b[j]; alive = lean_piece16<8, 64>(LL, id, rk, c, len, t); }
-                else if (!__ballot(len > 12)) { uint32_t c[13]; for (int j = 0; j < 13; j++) c[j] = b[j]; alive = lean_piece16<12, 64>(LL, id, rk, c, len, t); }
-                else alive = lean_piece16<16, 64>(LL, id, rk, b, len, t);
-                rk[0] = alive;                                                   // (slot 0 of the lane's key column is free now)
-                wave_lds_fence();
-                round_base = pn_head;
-                pn_head += nround;
-                STAMP_END(2);
-            }
-            // ---- pack every piece before the first one that still waits for a merge round
-            int k_bound = k_res < np ? k_res : np;
-            if (pn_head != pn_tail) k_bound = (int)(W.pend[pn_head & (ENC_PEND - 1)] & 0xFFFu);
-            k_bound = __builtin_amdgcn_readfirstlane(k_bound);
+        for (int kc = 0; kc < np; kc += 64) {
             STAMP_BEGIN();
-            for (int c = k_pack >> 6; c * 64 < k_bound; c++) {
-                STAMP_ADD(7, 1);
-                const int k = c * 64 + lane;
-                const bool act = k >= k_pack && k < k_bound;
-                const uint32_t rw = ring[__builtin_amdgcn_readfirstlane(c & (ENC_RING - 1))];
-                const uint32_t kind = (rw >> RW_KIND_SHIFT) & 3u, pay = rw >> RW_PAY_SHIFT, s = rw & RW_S_MASK;
-                const uint64_t bact = __ballot(act);
-                uint32_t pos, total;
-                if (!__ballot(act && kind != RW_TOKEN)) {
-                    // every piece a table entry: one token each
-                    pos = run + mbcnt64(bact);
-                    total = (uint32_t)__popcll(bact);
-                    if (act && store) out[pos] = pay;
-                } else {
-                    const bool ishard = act && kind == RW_HARD, islong = act && kind == RW_LONG;
-                    const uint32_t m = (pay - round_base) & (ENC_PEND - 1);          // the lane that merged this piece
-                    uint32_t alive = ishard ? W.rk[m] : 0u;
-                    uint32_t cn = act ? (kind == RW_TOKEN ? 1u : kind == RW_HARD ? (uint32_t)__popc(alive) : 0u) : 0u;
-                    uint32_t hd = 0;
-                    if (__ballot(islong)) {
-                        if (islong) {
-                            hd = w.htok[B + s];
-                            cn = (hd >> JTK_HT_CNT_SHIFT) & JTK_HT_CNT_MASK;
-                            if (cn == JTK_HT_ESCAPE) cn = w.docpre[B + s + 1];       // giant piece
-                        }
-                    }
-                    const uint32_t inc2 = wave_incl_scan_dpp(cn);
-                    pos = run + inc2 - cn;
-                    total = (uint32_t)__shfl((int)inc2, 63);
-                    if (store) {
-                        if (act && kind == RW_TOKEN) out[pos] = pay;
-                        // merged pieces: the ids of their live parts, in order
-                        uint32_t o = pos;
-                        while (__ballot(alive != 0u)) {
-                            if (alive) {
-                                const uint32_t j = (uint32_t)__builtin_ctz(alive);
-                                alive &= alive - 1u;
-                                out[o++] = W.id[j * 64 + m];
-                            }
-                        }
-                        if (__ballot(islong)) {
-                            if (islong && cn) {
-                                out[pos] = hd & JTK_HT_ID_MASK;
-                                const uint32_t* src = w.htok + B + s;
-                                for (uint32_t i = 1; i < cn; i++) out[pos + i] = src[i] & JTK_HT_ID_MASK;
-                            }
-                        }
-                    }
+            if (kc >= k0 + ENC_WIN) {
+                // list the starts of pieces k0 .. k0 + ENC_WIN (each lane: the set bits of its word)
+                k0 += ENC_WIN;
+                wave_lds_fence();
+                uint32_t i = pre;
+                for (uint64_t m = pm; m; m &= m - 1, i++) {
+                    const int rel = (int)i - k0;
+                    if (rel >= 0 && rel <= ENC_WIN) W.starts[rel] = (uint16_t)(lane * 64 + jtk_ctz64(m));
                 }
-                // document starts among these pieces: tokens of the strip before them
-                if (__ballot(act && (rw & RW_DOC))) { if (act && (rw & RW_DOC)) w.docpre[B + s] = pos; }
-                run += total;
+                if (lane == 0 && np - k0 <= ENC_WIN) W.starts[np - k0] = (uint16_t)end_rel;
+                wave_lds_fence();
             }
-            STAMP_END(3);
-            k_pack = k_bound;
+            const int k = kc + lane;
+            const bool have = k < np;
+            const int rel = have ? k - k0 : 0;
+            const uint32_t s = W.starts[rel], e = W.starts[rel + 1];
+            const uint32_t plen = e - s;
+            // a piece of <= 8 bytes and its primary slot in the tok8 table
+            uint32_t tx0, tx1;
+            if (!tail_strip) {
+                const U2Bytes v = *reinterpret_cast<const U2Bytes*>(w.text + B + s);
+                tx0 = v.x; tx1 = v.y;
+            } else {
+                const uint4 v = load_text16(w.text, B + s, n);
+                tx0 = v.x; tx1 = v.y;
+            }
+            const bool small = have && plen <= 8u;
+            const uint32_t len = small ? plen : 0u;
+            const uint64_t runm = ~0ull >> ((0u - 8u * len) & 63u);              // 8 len ones
+            const uint32_t key0 = tx0 & (uint32_t)runm, key1 = tx1 & (uint32_t)(runm >> 32);
+            const uint32_t mix = jtk_tok16_mix(key0, key1, 0u, 0u, len);
+            const uint4 ka = *reinterpret_cast<const uint4*>(tok + ((size_t)jtk_reduce32(mix, n8) << 4));   // lo, hi, id, len
+            bool hit = small && ((ka.x ^ key0) | (ka.y ^ key1) | ((ka.w & JTK_TOK_LEN_MASK) ^ len)) == 0u;
+            if (gaps) {                                                          // (wave-uniform; the shuffles are evaluated by all lanes)
+                const uint32_t glo = (uint32_t)__shfl((int)(uint32_t)gm, (int)(s >> 6)), ghi = (uint32_t)__shfl((int)(uint32_t)(gm >> 32), (int)(s >> 6));
+                if ((((s & 32u) ? ghi : glo) >> (s & 31u)) & 1u) hit = false;    // unmatched text is a hole without tokens
+            }
+            // dense pieces: the token, in order
+            const uint64_t bh = __ballot(hit);
+            if (hit && !w.count_only) out[run + mbcnt64(bh)] = ka.z;
+            run += (uint32_t)__popcll(bh);
+            // holes: a bit in the strip's bitmap and an entry in the pending ring
+            const uint64_t bo = __ballot(have && !hit);
+            if (bo) {
+                if (have && !hit) {
+                    const uint32_t hno = nholes + mbcnt64(bo);
+                    W.holes[(ho_tail + mbcnt64(bo)) & (ENC_PEND - 1)] = make_uint2(s | ((min(plen, 17u) - 1u) << 12) | (hno << 17), (uint32_t)strip);
+                }
+                ho_tail += (uint32_t)__popcll(bo);
+                nholes += (uint32_t)__popcll(bo);
+            }
+            if (lane == (kc >> 6)) hw = bo;
+            STAMP_END(1);
+            STAMP_ADD(4, 1);
+            // 64 holes wait: a batch (and before it a merge round, if the hard ring could not take the batch's pieces)
+            if (ho_tail - ho_head >= 64u) {
+                if (hd_tail - hd_head >= 64u) merge_round(64u);
+                hole_batch(64u);
+            }
         }
         asm volatile("" ::"v"(touch));
-        if (lane == 0) w.tile_tot[strip] = run;
+        // the strip's hole bitmap (one word per chunk) and its dense tokens' count
+        if (lane < ((np + 63) >> 6)) w.holebits[strip * 64 + lane] = hw;
+        if (lane == 0 && run) atomicAdd(&w.tile_tot[strip], run);
         STAMP_ADD(8, 1);
         STAMP_ADD(9, np);
+        STAMP_ADD(12, nholes);
     }
+    // ---- the wave's last holes and hard pieces
+    while (ho_tail != ho_head) {
+        if (hd_tail - hd_head >= 64u) merge_round(64u);
+        hole_batch(min(64u, ho_tail - ho_head));
+    }
+    while (hd_tail != hd_head) merge_round(min(64u, hd_tail - hd_head));
 #ifdef JTK_ENC_STAMP
     st_acc[0] = __builtin_amdgcn_s_memtime() - st_wave0;
     if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_enc_stamp[i], (unsigned long long)st_acc[i]);
@@ -376,16 +453,19 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// strip_gather: the strips' tokens (stok, dense per strip) to their place in the batch's packed output, once the
-// exclusive scan of the strips' counts (k_tile_scan) has said where that is.  One wave per strip; pure data movement.
+// strip_expand: the packed token stream.  One wave per strip, once the exclusive scan of the strips' token counts
+// (k_tile_scan) has said where its tokens go: pieces in order, 64 at a time -- a dense piece takes the next token of the
+// strip's dense block, a hole its record (hrec); a wave prefix sum of the counts gives every token its place.  Also leaves,
+// at every document's first byte, the tokens of its strip before it (docpre) for k_doc_offsets.
 // ---------------------------------------------------------------------------------------------------
-constexpr int GATHER_THREADS = 256;
+constexpr int EXPAND_THREADS = 256;
 
-__global__ void __launch_bounds__(GATHER_THREADS) k_strip_gather(JtkWork w) {
+__global__ void __launch_bounds__(EXPAND_THREADS) k_strip_expand(JtkWork w) {
     const int lane = threadIdx.x & 63;
-    const int64_t strip = (int64_t)blockIdx.x * (GATHER_THREADS / 64) + (threadIdx.x >> 6);
+    const int64_t strip = (int64_t)blockIdx.x * (EXPAND_THREADS / 64) + (threadIdx.x >> 6);
     if (strip >= w.n_tiles) return;
     const uint32_t total = w.tile_tot[strip];
+    const int np = (int)w.tile_np[strip];
     int64_t base;
     if (w.inline_scan) {
         // a small job (at most 1024 strips): the tokens before this strip, added up here -- one launch less
@@ -407,18 +487,91 @@ __global__ void __launch_bounds__(GATHER_THREADS) k_strip_gather(JtkWork w) {
             }
         }
     } else base = w.tile_off[strip];
-    if (w.count_only) return;
-    const uint32_t* src = w.stok + strip * T;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(w.tokens) + base;
-    // 16 bytes per lane where the destination allows: a head of up to three words, aligned quads, a tail
-    const uint32_t head = min(total, (uint32_t)((4u - (uint32_t)(base & 3)) & 3u));
-    if ((uint32_t)lane < head) dst[lane] = src[lane];
-    const uint32_t nq = (total - head) >> 2;
-    struct __attribute__((packed, aligned(4))) U4Words { uint32_t x, y, z, w; };
-    for (uint32_t q = (uint32_t)lane; q < nq; q += 64) {
-        const U4Words v = *reinterpret_cast<const U4Words*>(src + head + 4 * q);
-        *reinterpret_cast<uint4*>(dst + head + 4 * q) = make_uint4(v.x, v.y, v.z, v.w);
+    if (np == 0) return;
+    const int64_t B = strip * T;
+    const int nchunks = (np + 63) >> 6;
+    const bool store = w.count_only == 0;
+    // lane c: the hole mask of chunk c and the holes before it
+    const uint64_t hw = lane < nchunks ? w.holebits[strip * 64 + lane] : 0ull;
+    const uint32_t hc = (uint32_t)__popcll(hw);
+    const uint32_t hpre = wave_incl_scan_dpp(hc) - hc;
+    // document starts in this strip (each is a piece start): lane L keeps those of its mask word, with the pieces before the word
+    const int64_t wd = (B >> 6) + lane;
+    const uint64_t dm = (wd < w.n_words) ? w.docmask[wd] : 0ull;
+    uint64_t pm = 0;
+    uint32_t ppre = 0;
+    const bool any_doc = __ballot(dm != 0) != 0;
+    if (any_doc) {
+        pm = piece_word(w, wd);
+        if (wd * 64 + 63 >= w.n_bytes) pm &= (wd * 64 >= w.n_bytes) ? 0ull : ((1ull << (w.n_bytes - wd * 64)) - 1ull);
+        const uint32_t c = (uint32_t)__popcll(pm);
+        ppre = wave_incl_scan_dpp(c) - c;
     }
-    const uint32_t done = head + 4 * nq;
-    if (done + (uint32_t)lane < total) dst[done + lane] = src[done + lane];
+    const uint64_t dmp = dm & pm;                                        // (a document start that is no piece start here: the end sentinel)
+    const uint32_t pcnt = (uint32_t)__popcll(pm);
+    const uint32_t* const dense = w.stok + B;
+    const uint64_t* const hrec = w.hrec + B;
+    uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens) + base;
+    uint32_t run = 0;
+    for (int c = 0; c < nchunks; c++) {
+        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hw, c), whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hw >> 32), c);
+        const uint64_t word = ((uint64_t)whi << 32) | wlo;
+        const uint32_t hb = (uint32_t)__builtin_amdgcn_readlane((int)hpre, c);
+        const int k = c * 64 + lane;
+        const bool valid = k < np;
+        const bool ishole = ((word >> lane) & 1ull) != 0;                 // (bits of a chunk's mask beyond np are clear)
+        const uint32_t dbase = (uint32_t)(c * 64) - hb;                     // dense pieces before this chunk
+        uint32_t pos;
+        if (word == 0) {
+            // every piece a dense one: one token each
+            pos = run + (uint32_t)lane;
+            if (valid && store) dst[pos] = dense[dbase + (uint32_t)lane];
+            run += (uint32_t)min(64, np - c * 64);
+        } else {
+            const uint64_t vmask = (np - c * 64 >= 64) ? ~0ull : ((1ull << (np - c * 64)) - 1ull);
+            uint32_t tk = 0;
+            uint64_t rec = 0;
+            if (valid && !ishole) tk = dense[dbase + mbcnt64(~word & vmask)];
+            if (ishole) rec = hrec[hb + mbcnt64(word)];
+            const uint32_t kind = (uint32_t)(rec >> HR_KIND_SHIFT) & 3u;
+            uint32_t cn = valid ? 1u : 0u;
+            if (ishole) cn = kind == HR_TOKS ? (uint32_t)((rec >> 51) & 3u) + 1u : kind == HR_REF ? (uint32_t)(rec & 0x1FFFFFu) : 0u;
+            const uint32_t inc = wave_incl_scan_dpp(cn);
+            pos = run + inc - cn;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (store) {
+                if (ishole && kind == HR_TOKS) tk = (uint32_t)rec & JTK_HT_ID_MASK;
+                const bool isref = ishole && kind == HR_REF;
+                if (cn && !isref) dst[pos] = tk;
+                if (ishole && kind == HR_TOKS && cn > 1u) {
+                    dst[pos + 1] = (uint32_t)(rec >> 17) & JTK_HT_ID_MASK;
+                    if (cn > 2u) dst[pos + 2] = (uint32_t)(rec >> 34) & JTK_HT_ID_MASK;
+                }
+                if (__ballot(isref)) {
+                    if (isref) {
+                        const uint32_t* src = w.htok + B + ((uint32_t)(rec >> 21) & 0xFFFu);
+                        for (uint32_t i = 0; i < cn; i++) dst[pos + i] = src[i] & JTK_HT_ID_MASK;
+                    }
+                }
+            }
+        }
+        // document starts among these pieces: tokens of the strip before them (rare: one or two per strip)
+        if (any_doc) {
+            // lanes whose mask word holds a document start at one of this chunk's pieces
+            for (uint64_t todo = __ballot(dmp != 0 && ppre < (uint32_t)(c * 64 + 64) && ppre + pcnt > (uint32_t)(c * 64)); todo; todo &= todo - 1) {
+                const int L = jtk_ctz64(todo);
+                const uint64_t dL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dmp >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dmp, L);
+                const uint64_t pL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pm >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pm, L);
+                const uint32_t preL = (uint32_t)__builtin_amdgcn_readlane((int)ppre, L);
+                for (uint64_t d = dL; d; d &= d - 1) {
+                    const int bit = jtk_ctz64(d);
+                    const int kk = (int)(preL + (uint32_t)__popcll(pL & ((1ull << bit) - 1ull)));
+                    if (kk >= c * 64 && kk < c * 64 + 64) {
+                        const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)pos, kk - c * 64);
+                        if (lane == 0) w.docpre[B + L * 64 + bit] = pv;
+                    }
+                }
+            }
+        }
+    }
 }

@@ -37,12 +37,13 @@ def main():
         b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(off) - 1, len(text), ordinary=False, sync=True)
         lib.jtk_debug_stamps(buf)
         v = [int(x) for x in buf]
-        tot, res, mrg, pck = v[0], v[1], v[2], v[3]
+        tot, main, mrg, hol = v[0], v[1], v[2], v[3]
         strips, pieces = max(1, v[8]), v[9]
-        print("%-20s strip_encode %.3f ms | wave time: resolve %.0f%% merge %.0f%% pack %.0f%% other %.0f%% | per strip: %.0f pieces, %.1f resolve chunks, "
-              "%.2f rounds (%.0f%% of lanes), %.1f pack chunks, %.0f kcycles" % (
-                  name, b.kernel_times()["strip_encode"], 100.0 * res / tot, 100.0 * mrg / tot, 100.0 * pck / tot, 100.0 * (tot - res - mrg - pck) / tot,
-                  pieces / strips, v[4] / strips, v[5] / strips, 100.0 * v[6] / max(1, 64 * v[5]), v[7] / strips, (res + mrg + pck) / strips / 1e3), flush=True)
+        print("%-20s strip_encode %.3f ms expand %.3f ms | wave time: main %.0f%% hole batches %.0f%% merge %.0f%% other %.0f%% | per strip: %.0f pieces, %.0f holes (%.0f%%), "
+              "%.1f chunks, %.2f batches (%.0f%% of lanes), %.2f rounds (%.0f%% of lanes), %.0f memo hits, %.0f kcycles" % (
+                  name, b.kernel_times()["strip_encode"], b.kernel_times()["strip_expand"], 100.0 * main / tot, 100.0 * hol / tot, 100.0 * mrg / tot,
+                  100.0 * (tot - main - mrg - hol) / tot, pieces / strips, v[12] / strips, 100.0 * v[12] / max(1, pieces), v[4] / strips,
+                  v[10] / strips, 100.0 * v[11] / max(1, 64 * v[10]), v[5] / strips, 100.0 * v[6] / max(1, 64 * v[5]), v[13] / strips, (main + mrg + hol) / strips / 1e3), flush=True)
         del b, d_text, d_off
 
 
