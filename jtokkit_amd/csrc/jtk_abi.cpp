@@ -45,7 +45,7 @@ struct DevBuf {
 };
 
 constexpr int N_STAGES = 8;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "long_pieces", "strip_encode",
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "strip_encode", "bpe_merge",
                                            "tile_scan", "strip_expand", "doc_offsets"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -392,15 +392,16 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t nt = (size_t)w.n_tiles;
-    const size_t qcnt_bytes = JTK_NBINS * JTK_Q_SHARDS * 4;
+    w.n_shards = (uint32_t)jtk_strip_encode_grid(w.n_tiles);
+    const size_t qcnt_bytes = JTK_NBINS * (size_t)JTK_MAX_Q_SHARDS * 4;
     const size_t tot_bytes = align_up(nt * 4, 16);                  // tile_tot: zeroed with the masks and counters
     const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes + tot_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
-    const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
-    const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3};
+    const size_t tps = (nt + w.n_shards - 1) / w.n_shards;          // strips per queue shard (= workgroup of k_strip_encode)
+    const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4, JTK_BIN_CAP5, JTK_BIN_CAP6};
     size_t q_bytes = 0;
-    for (int k = 0; k < JTK_NBINS; k++) q_bytes += tps * caps[k] * JTK_Q_SHARDS * 8;
+    for (int k = 0; k < JTK_NBINS; k++) q_bytes += tps * caps[k] * w.n_shards * 16;
     int rc;
     if ((rc = cs.zeroed.ensure(zero_bytes)) || (rc = cs.piecemask.ensure(mask_bytes)) ||
         (rc = cs.stok.ensure(nt * JTK_TILE * 4)) || (rc = cs.hrec.ensure(nt * JTK_TILE * 8)) || (rc = cs.holebits.ensure(nt * 64 * 8)) ||
@@ -430,9 +431,9 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     {
         uint8_t* qp = (uint8_t*)cs.queues.p;
         for (int k = 0; k < JTK_NBINS; k++) {
-            w.qm[k] = (uint64_t*)qp;
+            w.qe[k] = (uint4*)qp;
             w.q_cap[k] = (int64_t)(tps * caps[k]);
-            qp += tps * caps[k] * JTK_Q_SHARDS * 8;
+            qp += tps * caps[k] * w.n_shards * 16;
         }
     }
     w.mid_list = (JtkLongPiece*)cs.mid_list.p;
@@ -594,13 +595,12 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
             jtk_launch_pretok_split(w, enc->dt, cst);
         }
         end();
-        begin();                                                    // pieces of more than 16 bytes: listed, merged, tokens in htok
-        jtk_launch_find_long(w, cst);
+        begin();                                                    // every strip: dense tokens, hole bitmap, hole records; merges queued
+        jtk_launch_strip_encode(w, enc->dt, cst);
+        end();
+        begin();                                                    // the queued pieces' hole records
         jtk_launch_long_shortcut(w, enc->dt, cst);                  // (only for rank tables with entries merging cannot reproduce)
         jtk_launch_bpe_merge(w, enc->dt, cst);
-        end();
-        begin();                                                    // every strip: pieces -> tokens (dense per strip) + its count
-        jtk_launch_strip_encode(w, enc->dt, cst);
         end();
         begin();
         if (fork && c > 0) HIP_TRY(hipStreamWaitEvent(cst, b->set[(c - 1) % n_sets].ev_scan, 0));

@@ -1,96 +1,81 @@
-// jtk_long_pieces.h -- pieces of more than JTK_SHORT_MAX bytes: found in the piece mask (k_find_long), looked up whole where
-// the rank table needs it (k_long_shortcut), merged (k_bpe_merge).  These kernels run BEFORE k_strip_encode, which then only
-// has to copy such a piece's tokens out of htok.  Included by jtk_kernels.hip inside its anonymous namespace.
+// jtk_bpe_merge.h -- k_bpe_merge: bytePairMerge (GptBytePairEncoding.java:200-275) of the pieces k_strip_encode queued, by
+// length bin, in one persistent launch; k_long_shortcut for rank tables that need the whole-piece lookup beyond 16 bytes.
+// Included by jtk_kernels.hip inside its anonymous namespace.
 
 // ---------------------------------------------------------------------------------------------------
-// find_long: one lane per piece-mask word.  A piece start whose next sixteen mask bits are all clear begins a piece of more
-// than JTK_SHORT_MAX bytes: a little mask algebra finds those starts (few or none per word in ordinary text), a scan of the
-// following words finds where each ends, and the piece is queued by length for k_bpe_merge -- or gets its htok header right
-// here when it is longer than the library accepts.
+// short bins of k_bpe_merge: the queued pieces of 4..16 bytes that are no table entry -- all but a handful of the pieces
+// that need merging -- ONE LANE PER PIECE (jtk_lean_merge.h).  The three bins (4..8, 9..12, 13..16 bytes) run the 8-, 12- and
+// 16-slot variants, so that a wave's pieces need about the same number of steps.  The bytes come straight from the text
+// (one unaligned 16-byte load); the result is the piece's hole record (more than three tokens: in htok), and -- when it
+// is at most six tokens -- an entry in this XCD's memo, so that k_strip_encode answers the piece's next occurrence itself.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t piece_word(const JtkWork& w, int64_t wd) {
-    // piece starts of mask word wd: positions before the chunk's first document and positions >= n start no piece here, but
-    // the end sentinel (bit n) stays: it ends the last piece
-    uint64_t m = (wd < w.n_words) ? w.piecemask[wd] : 0ull;
-    const int64_t n = w.n_bytes, p0 = wd * 64;
-    if (p0 + 63 > n) m &= (p0 > n) ? 0ull : ((2ull << (n - p0)) - 1ull);          // keep positions <= n
-    if (p0 < w.lead) m &= (p0 + 64 <= w.lead) ? 0ull : ~((1ull << (w.lead - p0)) - 1ull);
-    return m;
-}
-
-__device__ __forceinline__ uint32_t mbcnt64_(uint64_t m) {          // set bits of m below this lane
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-__global__ void __launch_bounds__(256) k_find_long(JtkWork w) {
-    // (a wave covers 64 consecutive mask words = one tile, so all its pieces go to the same queue shard: the wave claims its
-    // entries with ONE returning atomic per length class and round -- a lane holds at most four such pieces -- instead of
-    // one per piece: text with many long pieces made 2.6 ms of contended atomics out of 128 MB)
-    const int64_t wd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int64_t n = w.n_bytes;
-    uint64_t m = 0, all = 0, lo = 0;
-    if (wd * 64 < n) {
-        all = piece_word(w, wd);                                                  // with the sentinel: it ends pieces
-        m = all;
-        if (wd * 64 + 63 >= n) m &= (1ull << (n - wd * 64)) - 1ull;             // the sentinel starts no piece
-    }
-    if (!__ballot(m != 0)) return;
-    if (m) {
-        // lo: bit p set iff one of the bits p + 1 .. p + 16 of (all, next word) is set  (smear down by 1, 2, 4, 8 after a shift of one)
-        const uint64_t nx = piece_word(w, wd + 1);
-        uint64_t hi = nx >> 1;
-        lo = (all >> 1) | (nx << 63);
-        lo |= (lo >> 1) | (hi << 63); hi |= hi >> 1;
-        lo |= (lo >> 2) | (hi << 62); hi |= hi >> 2;
-        lo |= (lo >> 4) | (hi << 60); hi |= hi >> 4;
-        lo |= (lo >> 8) | (hi << 56);
-    }
-    uint64_t lg = m & ~lo;
-    if (lg && w.gapmask) lg &= ~w.gapmask[wd];                                    // unmatched text: no tokens
-    const int shard = (int)(((wd * 64) / T) % JTK_Q_SHARDS);
-    while (__ballot(lg != 0)) {
-        // this round: every lane's next long piece; cls: 0..3 queue bin, 4 mid, 5 long, 6 giant, 7 too long, 8 none
-        int cls = 8;
-        int64_t start = 0, len = 0;
-        if (lg) {
-            const int p = jtk_ctz64(lg);
-            lg &= lg - 1;
-            start = wd * 64 + p;
-            // where the piece ends: the next set bit (the sentinel at n at the latest)
-            int64_t end = -1;
-            const uint64_t rest = p < 63 ? all & ~((2ull << p) - 1ull) : 0ull;
-            if (rest) end = wd * 64 + jtk_ctz64(rest);
-            for (int64_t v = wd + 1; end < 0 && v < w.n_words; v++) {
-                const uint64_t mv = piece_word(w, v);
-                if (mv) end = v * 64 + jtk_ctz64(mv);
+template <int NS, int THREADS, int BIN>
+__device__ __forceinline__ void short_bin(const JtkWork& w, const JtkDeviceTables& t, const LeanLds& L, uint4* memo, uint32_t count, uint32_t kq, uint32_t K) {
+    const int tid = threadIdx.x;
+    const int shard = blockIdx.x % w.n_shards;
+    uint32_t* const id = L.id + tid;
+    uint32_t* const rk = L.rk + tid;
+    const uint4* const qe = w.qe[BIN] + (int64_t)shard * w.q_cap[BIN];
+    for (uint32_t base = kq * THREADS; base < count; base += K * THREADS) {
+        const uint32_t qi = base + (uint32_t)tid;
+        const bool have = qi < count;
+        uint4 ent = make_uint4(0, 0, 0, 0);
+        if (have) ent = qe[qi];
+        const uint64_t meta = ((uint64_t)ent.y << 32) | ent.x;
+        const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
+        const int len = have ? (int)((meta >> JTK_QE_LEN_SHIFT) & 31u) + 1 : 0;
+        const uint4 tx = load_text16(w.text, pos, w.n_bytes);
+        const uint32_t d4[4] = {tx.x, tx.y, tx.z, tx.w};
+        uint32_t b[NS + 1];
+#pragma unroll
+        for (int j = 0; j < NS; j++) b[j] = (d4[j >> 2] >> (8 * (j & 3))) & 255u;
+        b[NS] = 0;
+        const uint32_t alive = lean_piece16<NS, THREADS>(L, id, rk, b, len, t);
+        // emit (:270-273)
+        const uint32_t c = (uint32_t)__popc(alive);
+        const int64_t strip = pos / T;
+        const uint32_t s = (uint32_t)(pos % T);
+        if (have) {
+            uint64_t rec;
+            if (c <= 3u) {
+                uint32_t a = alive;
+                uint32_t tk[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { const uint32_t j = a ? (uint32_t)__builtin_ctz(a) : 0u; tk[i] = a ? id[j * THREADS] : 0u; a &= a - 1u; }
+                rec = (uint64_t)tk[0] | ((uint64_t)tk[1] << 17) | ((uint64_t)tk[2] << 34) | ((uint64_t)(c - 1u) << 51) | (HR_TOKS << HR_KIND_SHIFT);
+            } else {
+                uint32_t* dst = w.htok + pos;
+                uint32_t i = 0;
+                for (uint32_t a = alive; a; a &= a - 1u) dst[i++] = id[(uint32_t)__builtin_ctz(a) * THREADS];
+                rec = (uint64_t)c | ((uint64_t)s << 21) | (HR_REF << HR_KIND_SHIFT);
             }
-            if (end < 0 || end > n) end = n;
-            len = end - start;
-            cls = len <= 32 ? 0 : len <= 64 ? 1 : len <= 128 ? 2 : len <= JTK_BIN_MAXLEN ? 3 : len <= JTK_MID_CAP ? 4 : len <= JTK_LONG_CAP ? 5
-                  : len <= JTK_GIANT_CAP ? 6 : 7;
+            w.hrec[strip * T + ent.z] = rec;
         }
-        for (uint64_t todo = __ballot(cls < 7); todo;) {
-            const int c = __builtin_amdgcn_readlane(cls, jtk_ctz64(todo));
-            const uint64_t mask = __ballot(cls == c);
-            todo &= ~mask;
-            uint32_t* counter = c < JTK_NBINS ? &w.q_count[c * JTK_Q_SHARDS + shard] : c == 4 ? w.mid_count : c == 5 ? w.long_count : w.n_giant;
-            uint32_t base = 0;
-            if (lane == jtk_ctz64(mask)) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, jtk_ctz64(mask));
-            if (cls == c) {
-                const uint32_t i = base + mbcnt64_(mask);
-                if (c < JTK_NBINS) w.qm[c][(int64_t)shard * w.q_cap[c] + i] = (uint64_t)start | ((uint64_t)(len - 1) << JTK_QE_LEN_SHIFT);
-                else (c == 4 ? w.mid_list : c == 5 ? w.long_list : w.giant_list)[i] = JtkLongPiece{start, len};
+        if (memo) {
+            // remember the result under the piece's bytes (only the lane that claims an empty slot writes it)
+            const uint32_t ulen = (uint32_t)len;
+            const uint64_t runm = ~0ull >> ((0u - 8u * ulen) & 63u);
+            const bool big = ulen > 8u;
+            const uint64_t mlo = big ? ~0ull : runm, mhi = big ? runm : 0ull;
+            const uint32_t key0 = tx.x & (uint32_t)mlo, key1 = tx.y & (uint32_t)(mlo >> 32), key2 = tx.z & (uint32_t)mhi, key3 = tx.w & (uint32_t)(mhi >> 32);
+            if (have && c <= MEMO_MAX_TOKENS && key0 != 0u) {
+                const uint32_t mix = jtk_tok16_mix(key0, key1, key2, key3, ulen);
+                uint4* e = memo + (size_t)memo_slot(mix, w.memo_mask) * 2u;
+                unsigned long long* hi64 = reinterpret_cast<unsigned long long*>(e + 1) + 1;
+                // (a look first: scattered compare-and-swaps are slow, and most slots are taken after the first pieces)
+                if (*hi64 == 0ull && atomicCAS(hi64, 0ull, (unsigned long long)MEMO_BUSY) == 0ull) {
+                    uint32_t a = alive;
+                    uint64_t tk[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { const uint32_t j = a ? (uint32_t)__builtin_ctz(a) : 0u; tk[i] = a ? id[j * THREADS] : 0u; a &= a - 1u; }
+                    const uint32_t tag = memo_tag(mix);
+                    e[0] = make_uint4(key0, key1, key2, key3);
+                    reinterpret_cast<unsigned long long*>(e + 1)[0] = tk[0] | (tk[1] << 17) | (tk[2] << 34) | ((uint64_t)tag << 51);
+                    *hi64 = tk[3] | (tk[4] << 17) | (tk[5] << 34) | ((uint64_t)c << 51) | ((uint64_t)ulen << 54) | ((uint64_t)(tag & 31u) << 59);
+                }
             }
         }
-        if (cls == 7) {
-            // longer than the library accepts: the document gets a status, the piece no tokens
-            const int64_t d = find_doc(w, start);
-            if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
-            w.htok[start] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;
-            w.docpre[start + 1] = 0u;
-        }
+        add_strip_counts(w, (uint32_t)strip, have, c);
     }
 }
 
@@ -102,17 +87,18 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
     typedef typename std::conditional<(SLOTS > 32), uint64_t, uint32_t>::type M;
     const int tid = threadIdx.x;
     if (tid >= THREADS) return;
-    const int shard = blockIdx.x % JTK_Q_SHARDS;
+    const int shard = blockIdx.x % w.n_shards;
     uint32_t* const id = L.id + tid;
     uint32_t* const rk = L.rk + tid;
-    const uint64_t* const qm = w.qm[BIN] + (int64_t)shard * w.q_cap[BIN];
+    const uint4* const qe = w.qe[BIN] + (int64_t)shard * w.q_cap[BIN];
 
     for (uint32_t base = kq * THREADS; base < count; base += K * THREADS) {
         const uint32_t qi = base + (uint32_t)tid;
         bool have = qi < count;
-        uint64_t meta = 0;
-        if (have) meta = qm[qi];
-        if (meta & JTK_QE_DONE) have = false;                          // a table entry (k_long_shortcut): its result is in place
+        uint4 ent = make_uint4(0, 0, 0, 0);
+        if (have) ent = qe[qi];
+        const uint64_t meta = ((uint64_t)ent.y << 32) | ent.x;
+        if (meta & JTK_QE_DONE) have = false;                          // a table entry (k_long_shortcut): its record is in place
         const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
         const int len = have ? (int)((meta >> JTK_QE_LEN_SHIFT) & 255u) + 1 : 0;
         M alive;
@@ -150,7 +136,7 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
         const M one = 1;
         const M alive0 = (len >= (int)(8 * sizeof(M))) ? ~(M)0 : ((one << len) - one);
         alive = lean_steps<SLOTS, THREADS, false, M>(id, rk, alive0, reinterpret_cast<const uint8_t*>(t.pairs.buckets), t.pairs.bits);
-        // ---- emit (:270-273): the piece's tokens in htok, packed from its first byte position; the count rides in word 0
+        // ---- emit (:270-273): the piece's tokens in htok, packed from its first byte position; the hole record says how many
         const uint32_t c = sizeof(M) == 8 ? (uint32_t)__popcll((uint64_t)alive) : (uint32_t)__popc((uint32_t)alive);
         if (have) {
             uint32_t* dst = w.htok + pos;
@@ -158,10 +144,11 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
             for (M m = alive; m;) {
                 const uint32_t j = sizeof(M) == 8 ? (uint32_t)jtk_ctz64((uint64_t)m) : (uint32_t)__builtin_ctz((uint32_t)m);
                 m &= m - (M)1;
-                dst[idx] = id[j * THREADS] | (idx == 0 ? c << JTK_HT_CNT_SHIFT : 0u);
-                idx++;
+                dst[idx++] = id[j * THREADS];
             }
+            w.hrec[(pos / T) * T + ent.z] = (uint64_t)c | ((uint64_t)(pos % T) << 21) | (HR_REF << HR_KIND_SHIFT);
         }
+        add_strip_counts(w, (uint32_t)(pos / T), have, c);
     }
 }
 
@@ -246,11 +233,11 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
     uint32_t& s_next = L.next[BIN];
 
     // dense queue shard `shard`; this workgroup takes chunks kq, kq + K, kq + 2K, ... of it
-    const int shard = blockIdx.x % JTK_Q_SHARDS;
-    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
+    const int shard = blockIdx.x % w.n_shards;
+    const uint32_t kq = blockIdx.x / w.n_shards, K = gridDim.x / w.n_shards;
     const uint32_t count = L.count[BIN];
     if ((uint64_t)kq * M_CHUNK >= count) return;
-    const uint64_t* const queue = w.qm[BIN] + (int64_t)shard * w.q_cap[BIN];     // entries are read in aligned pairs
+    const uint4* const queue = w.qe[BIN] + (int64_t)shard * w.q_cap[BIN];
 
     const JtkBpLds bp{L.bpbits, L.bpcum, L.bpranks};
     const JtkPairTable pt = t.pairs;
@@ -269,6 +256,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
     uint32_t qi = 0;
     int64_t pos = 0;
     int len = 0, tpart = 0;
+    uint32_t hole = 0;
     constexpr int NW = (SLOTS + 63) / 64;
     uint64_t alive[NW];
     mask_init<NW>(alive, 0);
@@ -318,7 +306,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
         // (3) the trip's loads: four per lane, unconditional
         const uint4* a0 = dummy; const uint4* a1 = dummy; const uint4* a2 = dummy; const uint4* a3 = dummy;
         const int64_t tbase = (pos & ~(int64_t)15) + 64 * (int64_t)tpart;
-        if (st == ST_NEED) a0 = reinterpret_cast<const uint4*>(queue + (qi & ~1u));
+        if (st == ST_NEED) a0 = queue + qi;
         if (st == ST_TEXT) {
             const uint4* tx = reinterpret_cast<const uint4*>(w.text + tbase);
             a0 = tx;                                                  // reads stay inside the text buffer
@@ -335,7 +323,8 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
 
         // (4) consume
         if (st == ST_NEED) {
-            const uint64_t entry = (qi & 1u) ? (((uint64_t)v0.w << 32) | v0.z) : (((uint64_t)v0.y << 32) | v0.x);
+            const uint64_t entry = ((uint64_t)v0.y << 32) | v0.x;
+            hole = v0.z;
             pos = (int64_t)(entry & JTK_QE_POS_MASK);
             len = (int)((entry >> JTK_QE_LEN_SHIFT) & 255u) + 1;
             tpart = 0;
@@ -418,7 +407,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
             }
         }
         // (6) emit finished pieces (:270-273) last, so the stores drain under the next trip's work: the piece's tokens in htok,
-        // packed from its first byte position, the count in word 0
+        // packed from its first byte position; the hole record says how many
         const uint64_t b_emit = __ballot(st == ST_EMIT);
         if (b_emit && (__popcll(b_emit) >= EMIT_BATCH || !b_merge)) {
             if (st == ST_EMIT) {
@@ -432,10 +421,11 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
                     for (uint64_t m = alive[k]; m;) {
                         const int j = k * 64 + jtk_ctz64(m);
                         m &= m - 1;
-                        dst[idx] = id[j * THREADS] | (idx == 0 ? c << JTK_HT_CNT_SHIFT : 0u);
-                        idx++;
+                        dst[idx++] = id[j * THREADS];
                     }
                 }
+                w.hrec[(pos / T) * T + hole] = (uint64_t)c | ((uint64_t)(pos % T) << 21) | (HR_REF << HR_KIND_SHIFT);
+                atomicAdd(&w.tile_tot[pos / T], c);
                 st = ST_NEED;
             }
         }
@@ -494,7 +484,7 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
     for (uint32_t i = wave_id; i < cnt; i += n_waves) {
         const JtkLongPiece lp = list[i];
         if (lp.len <= 0) continue;                                 // found by k_long_shortcut
-        const int len = (int)lp.len;
+        const int len = lp.len;
         for (int j = lane; j < len; j += WAVE) {
             const uint32_t b0 = w.text[lp.start + j];
             s_id[j] = t.byte_rank[b0];
@@ -502,17 +492,20 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
         }
         wave_lds_fence();
         merge_piece_wave(s_id, s_rk, len, t.pairs);
-        // surviving ids, packed from the piece's first position; the count rides in word 0 (part 0 always survives)
+        // surviving ids, packed from the piece's first position
         uint32_t total = 0;
         for (int base = 0; base < len; base += WAVE) {
             const int j = base + lane;
             const bool alive = j < len && s_id[j] != JTK_ID_DEAD;
             const uint64_t bal = __ballot(alive);
             const uint32_t idx = total + (uint32_t)__popcll(bal & lanemask_lt());
-            if (alive && idx) w.htok[lp.start + idx] = s_id[j];
+            if (alive) w.htok[lp.start + idx] = s_id[j];
             total += (uint32_t)__popcll(bal);
         }
-        if (lane == 0) w.htok[lp.start] = s_id[0] | (total << JTK_HT_CNT_SHIFT);
+        if (lane == 0) {
+            w.hrec[(lp.start / T) * T + lp.hole] = (uint64_t)total | ((uint64_t)(lp.start % T) << 21) | (HR_REF << HR_KIND_SHIFT);
+            atomicAdd(&w.tile_tot[lp.start / T], total);
+        }
         wave_lds_fence();
     }
 }
@@ -547,7 +540,7 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = blockDim.x, NWV = NT >> 6;
     const JtkLongPiece lp = w.giant_list[gi];
     if (lp.len <= 0) return;                                      // found by k_long_shortcut (workgroup-uniform)
-    const int len = (int)lp.len;
+    const int len = lp.len;
     uint32_t* gid = w.htok + lp.start;
     uint32_t* grk = w.docpre + lp.start;
     const int nch = (len + CH - 1) / CH;
@@ -616,43 +609,39 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
         if (wv == 2 && c2 != c0 && c2 != c1) chunk_min(c2);
         __syncthreads();
     }
-    // emit (wave 0): surviving ids packed in place from the piece's first position (a survivor never moves up); the count
-    // goes to docpre[start + 1] (position start + 1 is inside the piece, so no document starts there and nobody else
-    // writes that word)
+    // emit (wave 0): surviving ids packed in place from the piece's first position (a survivor never moves up)
     if (wv == 0) {
         uint32_t total = 0;
-        uint32_t first = 0;
         for (int base = 0; base < len; base += WAVE) {
             const int j = base + lane;
             const uint32_t v = j < len ? gid[j] : JTK_ID_DEAD;
             const bool alive = v != JTK_ID_DEAD;
             const uint64_t bal = __ballot(alive);
             const uint32_t idx = total + (uint32_t)__popcll(bal & lanemask_lt());
-            if (base == 0) first = (uint32_t)__shfl((int)v, 0);
             if (alive && idx) gid[idx] = v;
             total += (uint32_t)__popcll(bal);
         }
         if (lane == 0) {
-            gid[0] = first | ((uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT);
-            grk[1] = total;                                        // docpre[start + 1]: the count (JTK_HT_ESCAPE)
+            w.hrec[(lp.start / T) * T + lp.hole] = (uint64_t)total | ((uint64_t)(lp.start % T) << 21) | (HR_REF << HR_KIND_SHIFT);
+            atomicAdd(&w.tile_tot[lp.start / T], total);
         }
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_bpe_merge: ONE persistent launch for bytePairMerge of every piece of more than JTK_SHORT_MAX bytes (listed by
-// k_find_long): the lean bins (17..32, 33..64 bytes: one lane per piece), the state-machine bins for pieces of up to 256
-// bytes, the wave-per-piece lists (<= 512, <= 8192 bytes) and the workgroup-per-piece giants.  All phases share the 128 KiB of
-// LDS parts and the staged tables; a workgroup barrier separates them (their LDS layouts differ), but there is no
-// device-wide barrier and no launch gap between them.  Ordinary text has few such pieces: most workgroups read the
-// counts and leave.  Every piece's tokens end in htok (count in word 0); k_strip_encode, which runs next, copies them
-// into its strip's token stream.
+// k_bpe_merge: ONE persistent launch for bytePairMerge of every piece that k_strip_encode queued: the short bins (4..16
+// bytes, one lane per piece), the lean bins of 17..32 and 33..64 bytes, the state-machine bins for pieces of up to 256
+// bytes, the wave-per-piece lists (<= 512, <= 8192 bytes) and the workgroup-per-piece giants.  All phases share the 128 KiB
+// of LDS parts and the staged tables; a workgroup barrier separates phases whose LDS layouts differ, but there is no
+// device-wide barrier and no launch gap between them, and on ordinary text the later phases find empty queues and cost
+// nothing.  Every piece's result is its hole record (and tokens in htok when they are more than three); its token count
+// is added to its strip's.
 // ---------------------------------------------------------------------------------------------------
 #ifndef JTK_ML_THREADS
 #define JTK_ML_THREADS 1024
 #endif
-constexpr int ML_THREADS = JTK_ML_THREADS;       // lanes per workgroup; 16 part slots x 8 bytes of LDS each
+constexpr int ML_THREADS = JTK_ML_THREADS;       // lanes (= pieces in flight) per workgroup; 16 part slots x 8 bytes of LDS each
 constexpr int ML_WORDS = 16 * ML_THREADS;
 constexpr int ML_WGS_PER_SHARD = JTK_M_WGS_PER_SHARD;
 
@@ -666,32 +655,50 @@ __global__ void __launch_bounds__(ML_THREADS) k_bpe_merge(JtkWork w, JtkDeviceTa
     __shared__ uint32_t s_next[JTK_NBINS];
     __shared__ uint32_t s_count[JTK_NBINS + 3];
     const int tid = threadIdx.x;
-    const int shard = blockIdx.x % JTK_Q_SHARDS;
-    const uint32_t kq = blockIdx.x / JTK_Q_SHARDS, K = gridDim.x / JTK_Q_SHARDS;
+    const int shard = blockIdx.x % w.n_shards;
+    const uint32_t kq = blockIdx.x / w.n_shards, K = gridDim.x / w.n_shards;
     if (tid < JTK_NBINS) {
         s_next[tid] = 0;
-        s_count[tid] = w.q_count[tid * JTK_Q_SHARDS + shard];
+        s_count[tid] = w.q_count[tid * w.n_shards + shard];
     }
     if (tid == JTK_NBINS) s_count[JTK_NBINS] = *w.mid_count;
     if (tid == JTK_NBINS + 1) s_count[JTK_NBINS + 1] = *w.long_count;
     if (tid == JTK_NBINS + 2) s_count[JTK_NBINS + 2] = *w.n_giant;
     __syncthreads();
     // (all the counts were read up front: a phase without work costs neither a global load nor a barrier)
-    const uint32_t n0 = s_count[0], n1 = s_count[1];
-    const bool w0 = kq * (uint32_t)(ML_THREADS / 2) < n0, w1 = kq * (uint32_t)(ML_THREADS / 4) < n1;
-    const bool rest = (s_count[2] | s_count[3] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
-    if (!(w0 || w1 || rest)) return;
+    const uint32_t n0 = s_count[0], n1 = s_count[1], n2 = s_count[2], n3 = s_count[3], n4 = s_count[4];
+    const bool rest = (s_count[5] | s_count[6] | s_count[JTK_NBINS] | s_count[JTK_NBINS + 1] | s_count[JTK_NBINS + 2]) != 0u;
+    // Each phase is a chain of dependent lookups (as many as its longest piece has merges).  When every bin of the shard
+    // fits one workgroup pass -- small batches, where those chains ARE the kernel's time -- the shard's workgroups take
+    // bins of their own, so the chains run side by side; otherwise every workgroup takes a slice of every bin.
+    const bool side_by_side = n0 <= (uint32_t)ML_THREADS && n1 <= (uint32_t)ML_THREADS && n2 <= (uint32_t)ML_THREADS &&
+                              n3 <= (uint32_t)(ML_THREADS / 2) && n4 <= (uint32_t)(ML_THREADS / 4) && K >= 4u;
+    const uint32_t Kx = side_by_side ? 1u : K, k = side_by_side ? 0u : kq;
+    bool w0, w1, w2, w3, w4;
+    if (side_by_side) {
+        w0 = kq == 0u && n0; w1 = kq == 1u && n1; w2 = kq == 2u && n2; w3 = kq == 3u && n3; w4 = kq == 3u && n4;
+    } else {
+        w0 = kq * (uint32_t)ML_THREADS < n0; w1 = kq * (uint32_t)ML_THREADS < n1; w2 = kq * (uint32_t)ML_THREADS < n2;
+        w3 = kq * (uint32_t)(ML_THREADS / 2) < n3; w4 = kq * (uint32_t)(ML_THREADS / 4) < n4;
+    }
+    if (!(w0 || w1 || w2 || w3 || w4 || rest)) return;
     for (int i = tid; i < 1024; i += ML_THREADS) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += ML_THREADS) s_bpranks[i] = t.bp.ranks[i];
     if (tid < 256) s_brank[tid] = t.byte_rank[tid];
     __syncthreads();
     const LeanLds LL{s_id, s_rk, JtkBpLds{s_bpbits, s_bpcum, s_bpranks}, s_brank};
-    if (w0) lean_bin<32, ML_THREADS / 2, 0>(w, t, LL, n0, kq, K);
-    if (w1) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 1>(w, t, LL, n1, kq, K); }
+    uint4* const memo = w.memo ? w.memo + (size_t)xcc_id() * ((size_t)w.memo_mask + 1u) * 2u : nullptr;   // this XCD's table
+    // (the three short bins share one LDS layout, [16 slots][1024 lanes], and a lane uses only its own column: no barrier
+    // between them)
+    if (w0) short_bin<8, ML_THREADS, 0>(w, t, LL, memo, n0, k, Kx);
+    if (w1) short_bin<12, ML_THREADS, 1>(w, t, LL, memo, n1, k, Kx);
+    if (w2) short_bin<16, ML_THREADS, 2>(w, t, LL, memo, n2, k, Kx);
+    if (w3) { __syncthreads(); lean_bin<32, ML_THREADS / 2, 3>(w, t, LL, n3, k, Kx); }
+    if (w4) { __syncthreads(); lean_bin<64, ML_THREADS / 4, 4>(w, t, LL, n4, k, Kx); }
     if (!rest) return;
     const MergeLds L{s_id, s_rk, s_bpbits, s_bpranks, s_bpcum, s_brank, s_next, s_count};
-    if (s_count[2]) { __syncthreads(); merge_bin<128, ML_WORDS / 128, 2>(w, t, L); }
-    if (s_count[3]) { __syncthreads(); merge_bin<256, ML_WORDS / 256, 3>(w, t, L); }
+    if (s_count[5]) { __syncthreads(); merge_bin<128, ML_WORDS / 128, 5>(w, t, L); }
+    if (s_count[6]) { __syncthreads(); merge_bin<256, ML_WORDS / 256, 6>(w, t, L); }
     // pieces of 257..512 bytes: every wave of the grid takes pieces, parts in its own 2 x 512 words
     const uint32_t wv = (uint32_t)tid >> 6;
     if (s_count[JTK_NBINS]) {
@@ -738,17 +745,19 @@ __device__ uint32_t long_lookup(const JtkWork& w, const JtkDeviceTables& t, int6
 
 __global__ void __launch_bounds__(256) k_long_shortcut(JtkWork w, JtkDeviceTables t) {
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
-    for (int bin = 0; bin < JTK_NBINS; bin++) {
-        for (int shard = 0; shard < JTK_Q_SHARDS; shard++) {
-            const uint32_t count = w.q_count[bin * JTK_Q_SHARDS + shard];
-            uint64_t* qm = w.qm[bin] + (int64_t)shard * w.q_cap[bin];
+    for (int bin = JTK_NBINS_SHORT; bin < JTK_NBINS; bin++) {
+        for (int shard = 0; shard < (int)w.n_shards; shard++) {
+            const uint32_t count = w.q_count[bin * w.n_shards + shard];
+            uint4* qe = w.qe[bin] + (int64_t)shard * w.q_cap[bin];
             for (uint32_t i = gtid; i < count; i += gn) {
-                const uint64_t meta = qm[i];
+                const uint4 ent = qe[i];
+                const uint64_t meta = ((uint64_t)ent.y << 32) | ent.x;
                 const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
                 const uint32_t id = long_lookup(w, t, pos, (int64_t)((meta >> JTK_QE_LEN_SHIFT) & 255u) + 1);
                 if (id != JTK_RANK_NONE) {
-                    w.htok[pos] = id | (1u << JTK_HT_CNT_SHIFT);      // header: one token
-                    qm[i] = meta | JTK_QE_DONE;
+                    w.hrec[(pos / T) * T + ent.z] = (uint64_t)id | (HR_TOKS << HR_KIND_SHIFT);   // one token
+                    atomicAdd(&w.tile_tot[pos / T], 1u);
+                    qe[i].y = ent.y | 0x80000000u;                    // JTK_QE_DONE
                 }
             }
         }
@@ -760,7 +769,8 @@ __global__ void __launch_bounds__(256) k_long_shortcut(JtkWork w, JtkDeviceTable
             const JtkLongPiece lp = list[i];
             const uint32_t id = long_lookup(w, t, lp.start, lp.len);
             if (id != JTK_RANK_NONE) {
-                w.htok[lp.start] = id | (1u << JTK_HT_CNT_SHIFT);    // header: one token
+                w.hrec[(lp.start / T) * T + lp.hole] = (uint64_t)id | (HR_TOKS << HR_KIND_SHIFT);   // one token
+                atomicAdd(&w.tile_tot[lp.start / T], 1u);
                 list[i].len = 0;
             }
         }

@@ -12,20 +12,27 @@
 // A STRIP is the unit of the encode kernel: 4096 bytes = 64 piece-mask words, one per lane of the wave that encodes it.
 // Token counts, the scan and the per-document offsets are kept per strip ("tile" in the names below).
 #define JTK_TILE 4096
-// Pieces of more than JTK_SHORT_MAX bytes are merged BEFORE the strips are encoded: k_find_long lists them by length bin in
-// dense, sharded queues (the shard of a piece: its tile % JTK_Q_SHARDS; an entry is pos (37 bits) | (len - 1) << 37),
-// k_bpe_merge merges them and leaves each piece's tokens in htok, packed from the piece's first byte position, with the count
-// in word 0 (id | count << 17).  Pieces of up to JTK_SHORT_MAX bytes never leave the wave that encodes their strip.
+// Pieces that need bytePairMerge are queued by k_strip_encode for k_bpe_merge, by length bin, in dense queues, one per bin and
+// SHARD = workgroup of k_strip_encode (which claims its entries with an atomic in LDS: no global atomic on this path -- a
+// few counters shared by the whole grid took 1 ns per claim, 5 ms per GiB of mixed text).  An entry is 16 bytes:
+//   x, y  pos (37 bits) | (len - 1) << 37   (JTK_QE_DONE: found by k_long_shortcut, nothing left to merge)
+//   z     hole number of the piece in its strip (where its record goes: hrec[strip * JTK_TILE + z])
+// Bins 0..2 are pieces of up to JTK_SHORT_MAX bytes that are no table entry (the whole-piece lookup was made by
+// k_strip_encode), bins 3..6 longer ones (for which the rank table's entries of more than 16 bytes are found by merging).
 #define JTK_SHORT_MAX 16
 #define JTK_QE_POS_MASK ((1ull << 37) - 1ull)
 #define JTK_QE_LEN_SHIFT 37
-#define JTK_QE_DONE (1ull << 63)       // the piece is a table entry found by k_long_shortcut: its result is in place already
-#define JTK_NBINS 4                    // queue bins: pieces of 17..32, ..64, ..128, ..256 bytes
-#define JTK_Q_SHARDS 64
-#define JTK_BIN_CAP0 (JTK_TILE / 16)   // per tile: pieces of 17..32 bytes
-#define JTK_BIN_CAP1 (JTK_TILE / 32)   //           33..64 bytes
-#define JTK_BIN_CAP2 (JTK_TILE / 64)   //           65..128 bytes
-#define JTK_BIN_CAP3 (JTK_TILE / 128)  //           129..256 bytes
+#define JTK_QE_DONE (1ull << 63)
+#define JTK_NBINS 7                    // queue bins: pieces of 4..8, 9..12, 13..16, 17..32, ..64, ..128, ..256 bytes
+#define JTK_NBINS_SHORT 3
+#define JTK_MAX_Q_SHARDS 1024
+#define JTK_BIN_CAP0 (JTK_TILE / 4)    // per strip: pieces of 4..8 bytes (2..3-byte pieces never need the pair table)
+#define JTK_BIN_CAP1 (JTK_TILE / 8)    //            9..12 bytes
+#define JTK_BIN_CAP2 320               //            13..16 bytes (4096 / 13 = 315)
+#define JTK_BIN_CAP3 (JTK_TILE / 16)   //            17..32 bytes
+#define JTK_BIN_CAP4 (JTK_TILE / 32)   //            33..64 bytes
+#define JTK_BIN_CAP5 (JTK_TILE / 64)   //            65..128 bytes
+#define JTK_BIN_CAP6 (JTK_TILE / 128)  //            129..256 bytes
 #define JTK_BIN_MAXLEN 256            // longer pieces go to the wave-per-piece phases
 #define JTK_M_WGS_PER_SHARD 4
 #define JTK_MID_CAP 512          // wave-per-piece phase, small bin: pieces of 257..512 bytes
@@ -56,15 +63,12 @@ struct JtkDeviceTables {
     uint8_t special[JTK_MAX_SPECIALS][JTK_SPECIAL_MAXLEN];
 };
 
-// htok header word of a long piece: first token id | token count << 17
 #define JTK_HT_ID_MASK 0x1FFFFu
-#define JTK_HT_CNT_SHIFT 17
-#define JTK_HT_CNT_MASK 0x3FFFu
-#define JTK_HT_ESCAPE 0x3FFFu            // count does not fit (giant piece): the count is in docpre[pos + 1]
 
-struct JtkLongPiece {
+struct JtkLongPiece {       // a piece of more than JTK_BIN_MAXLEN bytes
     int64_t start;
-    int64_t len;
+    int32_t len;            // (0: found by k_long_shortcut)
+    uint32_t hole;          // its hole number in its strip
 };
 
 struct JtkResult {          // of a whole batch (all its chunks)
@@ -101,15 +105,15 @@ struct JtkWork {
     uint32_t* tile_np;      // [n_tiles] pieces of the strip
     uint4* memo;            // NULL, or [8 XCDs][memo_mask + 1][2]: merged pieces remembered for the rest of the job (jtk_strip_encode.h)
     uint32_t memo_mask;
-    uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a long piece (> JTK_SHORT_MAX bytes), packed from the piece's first
-                            // byte position (k <= len words); word 0 also carries the count k: id | k << 17
-                            // (JTK_HT_ESCAPE: the count is in docpre[pos + 1])
+    uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece that became more than three tokens, packed from the
+                            // piece's first byte position (k <= len words; their hole record says how many)
     uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its strip before it (sparse)
     uint32_t* tile_tot;     // [n_tiles] tokens of the strip (zeroed per job; k_strip_encode adds to it)
     int64_t* tile_off;      // [n_tiles + 1] exclusive scan of tile_tot
-    uint64_t* qm[JTK_NBINS];        // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k: position and length
+    uint4* qe[JTK_NBINS];           // [n_shards][q_cap[k]] queue entries of bin k
     int64_t q_cap[JTK_NBINS];       // entries per shard
-    uint32_t* q_count;              // [JTK_NBINS][JTK_Q_SHARDS]
+    uint32_t* q_count;              // [JTK_NBINS][n_shards] (written by each workgroup of k_strip_encode when it is done)
+    uint32_t n_shards;              // = the grid of k_strip_encode
     JtkLongPiece* mid_list; // pieces of 257..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
     JtkLongPiece* giant_list;// pieces longer than JTK_LONG_CAP
@@ -169,10 +173,10 @@ void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_mark_pieces(const JtkWork& w, const int64_t* begin, const int64_t* end, int64_t n_pieces, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
-void jtk_launch_find_long(const JtkWork& w, hipStream_t s);                                   // pieces of > JTK_SHORT_MAX bytes -> queues
+int jtk_strip_encode_grid(int64_t n_tiles);                                                   // workgroups of k_strip_encode = queue shards
+void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // every strip: dense tokens, hole bitmap, hole records; queues
 void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);     // only if t.longtok.n
-void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);         // ... merged, tokens in htok
-void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // every strip: dense tokens, hole bitmap, hole records
+void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);         // the queued pieces' hole records
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_strip_expand(const JtkWork& w, hipStream_t s);                                // ... -> tokens, docpre
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s);

@@ -413,8 +413,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
 constexpr int T = JTK_TILE;
 
 #include "jtk_lean_merge.h"
-#include "jtk_long_pieces.h"
+#include "jtk_strip_common.h"
 #include "jtk_strip_encode.h"
+#include "jtk_bpe_merge.h"
 
 // ---------------------------------------------------------------------------------------------------
 // tile_scan: exclusive scan of the tokens per tile (tile_tot: the resolved pieces counted by piece_resolve plus
@@ -571,25 +572,25 @@ void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStre
     if (t.kind == JTK_PAT_CL100K) hipLaunchKernelGGL(k_pretok_split<JTK_PAT_CL100K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
     else hipLaunchKernelGGL(k_pretok_split<JTK_PAT_R50K>, dim3((unsigned)tiles), dim3(SPLIT_THREADS), 0, s, w, t);
 }
-void jtk_launch_find_long(const JtkWork& w, hipStream_t s) {
-    const int64_t nw = (w.n_bytes + 63) / 64;
-    if (nw > 0) hipLaunchKernelGGL(k_find_long, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, w);
+int jtk_strip_encode_grid(int64_t n_tiles) {
+    // two workgroups of 12 waves per CU hold it for the whole launch; small jobs spread their strips over as many CUs as they have
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+    int64_t full = (int64_t)n_cu * ENC_WGS_PER_CU;
+    if (full > JTK_MAX_Q_SHARDS) full = JTK_MAX_Q_SHARDS;
+    int64_t wgs = n_tiles < full * ENC_WAVES ? (n_tiles < full ? n_tiles : full) : full;   // few strips: one wave each on as many CUs as possible
+    return (int)(wgs < 1 ? 1 : wgs);
+}
+void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
+    hipLaunchKernelGGL(k_strip_encode, dim3(w.n_shards), dim3(ENC_THREADS), 0, s, w, t);
 }
 void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     if (t.longtok.n) hipLaunchKernelGGL(k_long_shortcut, dim3(256), dim3(256), 0, s, w, t);
 }
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    hipLaunchKernelGGL(k_bpe_merge, dim3(JTK_Q_SHARDS * ML_WGS_PER_SHARD), dim3(ML_THREADS), 0, s, w, t);
-}
-void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
-    // one workgroup per CU holds it for the whole launch (its LDS is the CU's); small jobs spread their strips over more CUs
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
-    int64_t wgs = (w.n_tiles + ENC_WAVES - 1) / ENC_WAVES;
-    if (w.n_tiles < (int64_t)n_cu * ENC_WAVES) wgs = w.n_tiles < n_cu ? w.n_tiles : n_cu;     // few strips: one wave each on as many CUs as possible
-    if (wgs > n_cu) wgs = n_cu;
-    if (wgs < 1) wgs = 1;
-    hipLaunchKernelGGL(k_strip_encode, dim3((unsigned)wgs), dim3(ENC_THREADS), 0, s, w, t);
+    // every queue shard gets at least one workgroup; few shards (a small job) get several each, so that their bins run side by side
+    const unsigned per = w.n_shards >= 256u ? 1u : (256u + w.n_shards - 1u) / w.n_shards;
+    hipLaunchKernelGGL(k_bpe_merge, dim3(w.n_shards * per), dim3(ML_THREADS), 0, s, w, t);
 }
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((w.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK)), dim3(1024), 0, s, w);

@@ -26,89 +26,18 @@
 #ifndef JTK_ENC_WAVES
 #define JTK_ENC_WAVES 12
 #endif
-constexpr int ENC_WAVES = JTK_ENC_WAVES, ENC_THREADS = 64 * ENC_WAVES;
+#ifndef JTK_ENC_WGS_PER_CU
+#define JTK_ENC_WGS_PER_CU 2
+#endif
+constexpr int ENC_WAVES = JTK_ENC_WAVES, ENC_THREADS = 64 * ENC_WAVES, ENC_WGS_PER_CU = JTK_ENC_WGS_PER_CU;
 constexpr int ENC_WIN = 512;                   // piece starts listed in LDS at a time
 constexpr int ENC_PEND = 128;                  // ring of pending holes / hard pieces (at most 127 wait)
 static_assert(T == 4096, "a strip is 64 mask words: one per lane");
 
-// hole record (8 bytes)
-constexpr int HR_KIND_SHIFT = 53;              // bits 53..54
-constexpr uint64_t HR_TOKS = 0;                // bits 0..50: up to three token ids, 17 bits each; bits 51..52: count - 1
-constexpr uint64_t HR_REF = 1;                 // bits 0..20: count; bits 21..32: offset of the piece in the strip: tokens in htok
-constexpr uint64_t HR_GAP = 2;                 // no tokens
-
-// Memo of merged pieces (per XCD, insert-only, cleared per job): a piece of 4..16 bytes that bytePairMerge turned into at most
-// six tokens is remembered under its bytes, so that its next occurrence -- natural text repeats its words -- costs one
-// lookup in the hole batch instead of a merge.  An entry is 32 bytes: the piece's 16 key bytes | lo64 | hi64 with
-//   lo64 = tokens 0..2 (17 bits each) | tag13 << 51;   hi64 = tokens 3..5 | count << 51 | len << 54 | tag5 << 59.
-// Only the wave that claims an empty slot (compare-and-swap of hi64 from 0 to MEMO_BUSY) ever writes it, and never again, so
-// each of the entry's words is either still zero or final: a reader that finds its key, its length and both tags (nonzero,
-// taken from the key's hash) has read a complete entry of exactly its key; anything else is a miss, and a miss only costs the
-// merge.  Each XCD has its own table: its L2 is the point of coherence for all its CUs, and nothing crosses XCDs.
-constexpr uint64_t MEMO_BUSY = 1ull << 51;
-constexpr uint32_t MEMO_MAX_TOKENS = 6;
-
-__device__ __forceinline__ uint32_t xcc_id() {
-    uint32_t x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    return x & 7u;
-}
-__device__ __forceinline__ uint32_t memo_slot(uint32_t mix, uint32_t mask) { return (jtk_pair_mix2(mix) ^ (mix >> 9)) & mask; }
-__device__ __forceinline__ uint32_t memo_tag(uint32_t mix) { return ((mix >> 17) & 0x1FFFu) | 1u; }
-
 struct __attribute__((aligned(16))) EncWaveLds {
-    uint32_t id[16 * 64];                      // parts of the pieces being merged: token ids, [slot][lane] ...
-    uint32_t rk[16 * 64];                      // ... and pair keys
     uint2 holes[ENC_PEND];                     // pending holes:  x = offset (12) | (min(len, 17) - 1) << 12 | hole number << 17, y = strip
-    uint2 hard[ENC_PEND];                      // pending pieces for bytePairMerge: the same
     uint16_t starts[ENC_WIN + 8];              // byte offsets of pieces k0 .. k0 + ENC_WIN (one more: where the last ends)
 };
-
-struct __attribute__((packed, aligned(1))) U4Bytes { uint32_t x, y, z, w; };
-struct __attribute__((packed, aligned(1))) U2Bytes { uint32_t x, y; };
-
-// the 16 bytes at text position p (bytes at or beyond n read as zero); p + 16 <= n is the fast path
-__device__ __forceinline__ uint4 load_text16(const uint8_t* text, int64_t p, int64_t n) {
-    if (p + 16 <= n) {
-        const U4Bytes v = *reinterpret_cast<const U4Bytes*>(text + p);
-        return make_uint4(v.x, v.y, v.z, v.w);
-    }
-    uint32_t tmp[4] = {0, 0, 0, 0};
-    for (int j = 0; j < 16; j++) if (p + j < n) tmp[j >> 2] |= (uint32_t)text[p + j] << (8 * (j & 3));
-    return make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-}
-
-// inclusive prefix sum across the wave with DPP row shifts and row broadcasts (six adds)
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);     // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);     // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);     // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);     // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) { return mbcnt64_(m); }
-
-// Token counts of a batch of lanes to tile_tot: the lanes' strips come in runs (ring order is text order), so the first
-// lane of each run adds the run's sum.  All lanes call this; lanes without a piece pass have = false.
-__device__ __forceinline__ void add_strip_counts(const JtkWork& w, uint32_t strip, bool have, uint32_t cc) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t key = have ? strip : 0xFFFFFFFFu;
-    const uint32_t c = have ? cc : 0u;
-    const uint32_t inc = wave_incl_scan_dpp(c);
-    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
-    const bool head = lane == 0 || prev != key;
-    const uint64_t heads = __ballot(head);
-    const uint64_t later = heads & ~((2ull << lane) - 1ull);                  // run heads after this lane
-    const int last = later ? jtk_ctz64(later) - 1 : 63;                        // last lane of this lane's run
-    const uint32_t run_end = (uint32_t)__shfl((int)inc, last);
-    if (head && have) {
-        const uint32_t sum = run_end - (inc - c);
-        if (sum) atomicAdd(&w.tile_tot[strip], sum);
-    }
-}
 
 #ifdef JTK_ENC_STAMP
 // diagnostic build: wave cycles per phase, summed over the launch (never read by the kernels; jtk_debug_stamps() fetches them)
@@ -122,24 +51,24 @@ __device__ unsigned long long g_enc_stamp[16];
 #define STAMP_ADD(i, v)
 #endif
 
-__global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDeviceTables t) {
+constexpr int ENC_WAVES_PER_EU = ENC_WAVES * ENC_WGS_PER_CU / 4;
+__global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, ENC_WAVES_PER_EU))) k_strip_encode(JtkWork w, JtkDeviceTables t) {
     __shared__ uint64_t s_bpbits[1024];
     __shared__ uint32_t s_bpranks[JTK_BP_MAX];
     __shared__ uint16_t s_bpcum[1024];
     __shared__ uint32_t s_brank[256];
     __shared__ EncWaveLds s_wave[ENC_WAVES];
+    __shared__ uint32_t s_qcount[JTK_NBINS];       // entries this workgroup has put in its queue of each bin
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < 1024; i += ENC_THREADS) { s_bpbits[i] = t.bp.bits[i]; s_bpcum[i] = t.bp.cum[i]; }
     for (int i = tid; i < JTK_BP_MAX; i += ENC_THREADS) s_bpranks[i] = t.bp.ranks[i];
     if (tid < 256) s_brank[tid] = t.byte_rank[tid];
+    if (tid < JTK_NBINS) s_qcount[tid] = 0;
     __syncthreads();
-    // (from here on the waves are independent: no workgroup barrier)
+    // (from here on the waves are independent: no workgroup barrier until the end)
     EncWaveLds& W = s_wave[wv];
-    uint32_t* const id = W.id + lane;
-    uint32_t* const rk = W.rk + lane;
     const JtkBpLds bp{s_bpbits, s_bpcum, s_bpranks};
-    const LeanLds LL{W.id, W.rk, bp, s_brank};
     const int64_t n = w.n_bytes;
     const bool gaps = w.gapmask != nullptr;
     const uint8_t* const tok = reinterpret_cast<const uint8_t*>(t.tok8.slots);   // the tok8 slots, then the tok16 slots: one allocation
@@ -151,79 +80,13 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
 #endif
     uint4* const memo = w.memo ? w.memo + (size_t)xcc_id() * ((size_t)w.memo_mask + 1u) * 2u : nullptr;   // this XCD's table
     uint32_t ho_head = 0, ho_tail = 0;            // pending holes  [head, tail)   (wave-uniform)
-    uint32_t hd_head = 0, hd_tail = 0;            // pending hard pieces
-
-    // ---- one merge round: a lane per pending hard piece (GptBytePairEncoding.java:200-275)
-    auto merge_round = [&](uint32_t nl) {
-        STAMP_BEGIN();
-        STAMP_ADD(5, 1);
-        STAMP_ADD(6, nl);
-        wave_lds_fence();
-        const bool mine = (uint32_t)lane < nl;
-        const uint2 pe = W.hard[(hd_head + (uint32_t)lane) & (ENC_PEND - 1)];
-        const uint32_t strip = pe.y, s = pe.x & 0xFFFu, h = pe.x >> 17;
-        const int len = mine ? (int)((pe.x >> 12) & 31u) + 1 : 0;
-        const int64_t pos = mine ? (int64_t)strip * T + s : 0;
-        const uint4 tx = load_text16(w.text, pos, n);
-        const uint32_t d4[4] = {tx.x, tx.y, tx.z, tx.w};
-        uint32_t b[17];
-#pragma unroll
-        for (int j = 0; j < 16; j++) b[j] = (d4[j >> 2] >> (8 * (j & 3))) & 255u;
-        b[16] = 0;
-        uint32_t alive;
-        // the round's longest piece picks the unrolled variant: 8, 12 or 16 slots
-        if (!__ballot(len > 8)) { uint32_t c[9]; for (int j = 0; j < 9; j++) c[j] = b[j]; alive = lean_piece16<8, 64>(LL, id, rk, c, len, t); }
-        else if (!__ballot(len > 12)) { uint32_t c[13]; for (int j = 0; j < 13; j++) c[j] = b[j]; alive = lean_piece16<12, 64>(LL, id, rk, c, len, t); }
-        else alive = lean_piece16<16, 64>(LL, id, rk, b, len, t);
-        // emit (:270-273): the hole record; more than three tokens go to htok, packed from the piece's first byte position
-        const uint32_t c = (uint32_t)__popc(alive);
-        if (mine) {
-            uint64_t rec;
-            if (c <= 3u) {
-                uint32_t a = alive;
-                uint32_t tk[3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) { const uint32_t j = a ? (uint32_t)__builtin_ctz(a) : 0u; tk[i] = a ? id[j * 64] : 0u; a &= a - 1u; }
-                rec = (uint64_t)tk[0] | ((uint64_t)tk[1] << 17) | ((uint64_t)tk[2] << 34) | ((uint64_t)(c - 1u) << 51) | (HR_TOKS << HR_KIND_SHIFT);
-            } else {
-                uint32_t* dst = w.htok + pos;
-                uint32_t i = 0;
-                for (uint32_t a = alive; a; a &= a - 1u) dst[i++] = id[(uint32_t)__builtin_ctz(a) * 64];
-                rec = (uint64_t)c | ((uint64_t)s << 21) | (HR_REF << HR_KIND_SHIFT);
-            }
-            w.hrec[(int64_t)strip * T + h] = rec;
-        }
-        if (memo) {
-            // remember the result under the piece's bytes (only the lane that claims an empty slot writes it)
-            const uint32_t ulen = (uint32_t)len;
-            const uint64_t runm = ~0ull >> ((0u - 8u * ulen) & 63u);
-            const bool big = ulen > 8u;
-            const uint64_t mlo = big ? ~0ull : runm, mhi = big ? runm : 0ull;
-            const uint32_t key0 = tx.x & (uint32_t)mlo, key1 = tx.y & (uint32_t)(mlo >> 32), key2 = tx.z & (uint32_t)mhi, key3 = tx.w & (uint32_t)(mhi >> 32);
-            if (mine && c <= MEMO_MAX_TOKENS && key0 != 0u) {
-                const uint32_t mix = jtk_tok16_mix(key0, key1, key2, key3, ulen);
-                uint4* e = memo + (size_t)memo_slot(mix, w.memo_mask) * 2u;
-                unsigned long long* hi64 = reinterpret_cast<unsigned long long*>(e + 1) + 1;
-                if (atomicCAS(hi64, 0ull, (unsigned long long)MEMO_BUSY) == 0ull) {
-                    uint32_t a = alive;
-                    uint64_t tk[6];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { const uint32_t j = a ? (uint32_t)__builtin_ctz(a) : 0u; tk[i] = a ? id[j * 64] : 0u; a &= a - 1u; }
-                    const uint32_t tag = memo_tag(mix);
-                    e[0] = make_uint4(key0, key1, key2, key3);
-                    reinterpret_cast<unsigned long long*>(e + 1)[0] = tk[0] | (tk[1] << 17) | (tk[2] << 34) | ((uint64_t)tag << 51);
-                    *hi64 = tk[3] | (tk[4] << 17) | (tk[5] << 34) | ((uint64_t)c << 51) | ((uint64_t)ulen << 54) | ((uint64_t)(tag & 31u) << 59);
-                }
-            }
-        }
-        add_strip_counts(w, strip, mine, c);
-        wave_lds_fence();
-        hd_head += nl;
-        STAMP_END(2);
-    };
 
     // ---- one hole batch: a lane per pending hole -- everything the main path does not do
     auto hole_batch = [&](uint32_t nl) {
+#ifdef JTK_EXP_NOBATCH                                                        // (timing experiment: results are wrong)
+        ho_head += nl;
+        return;
+#endif
         STAMP_BEGIN();
         STAMP_ADD(10, 1);
         STAMP_ADD(11, nl);
@@ -271,12 +134,17 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
         uint64_t rec = (uint64_t)tokid | (HR_TOKS << HR_KIND_SHIFT);            // one token
         uint32_t cnt = hit ? 1u : 0u;
         if (gap) rec = HR_GAP << HR_KIND_SHIFT;
+        // a piece of more than 16 bytes: its exact length from the mask (the next piece start, the end sentinel at the latest)
+        int64_t plen = len;
         if (__ballot(islong)) {
             if (islong) {
-                // merged by k_bpe_merge: the count is in the header word (giant pieces: docpre[pos + 1])
-                cnt = (w.htok[pos] >> JTK_HT_CNT_SHIFT) & JTK_HT_CNT_MASK;
-                if (cnt == JTK_HT_ESCAPE) cnt = w.docpre[pos + 1];
-                rec = (uint64_t)cnt | ((uint64_t)s << 21) | (HR_REF << HR_KIND_SHIFT);
+                int64_t v = pos >> 6;
+                uint64_t m = piece_word(w, v);
+                m = (pos & 63) == 63 ? 0ull : m & ~((2ull << (pos & 63)) - 1ull);
+                while (m == 0 && ++v < w.n_words) m = piece_word(w, v);
+                int64_t end = m ? v * 64 + jtk_ctz64(m) : n;
+                if (end > n) end = n;
+                plen = end - pos;
             }
         }
         bool hard = mine && shortp && !hit && !gap;
@@ -325,12 +193,45 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
                 STAMP_ADD(13, __popcll(__ballot(ok)));
             }
         }
-        if (mine && !hard) w.hrec[(int64_t)strip * T + h] = rec;
-        add_strip_counts(w, strip, mine && !hard, cnt);
-        // the rest needs bytePairMerge: on to the hard ring (text order is kept)
-        const uint64_t hb = __ballot(hard);
-        if (hard) W.hard[(hd_tail + mbcnt64(hb)) & (ENC_PEND - 1)] = pe;
-        hd_tail += (uint32_t)__popcll(hb);
+        // what is left needs bytePairMerge: queued for k_bpe_merge by length bin, in this workgroup's own queues (the wave claims
+        // its entries with one atomic in LDS per bin)
+        int cls = -1;                                                            // 0..6 queue bin, 7 mid, 8 long, 9 giant
+        if (hard) cls = len <= 8u ? 0 : len <= 12u ? 1 : 2;
+        if (islong) {
+            cls = plen <= 32 ? 3 : plen <= 64 ? 4 : plen <= 128 ? 5 : plen <= JTK_BIN_MAXLEN ? 6 : plen <= JTK_MID_CAP ? 7 : plen <= JTK_LONG_CAP ? 8
+                  : plen <= JTK_GIANT_CAP ? 9 : -1;
+            if (cls < 0) {
+                // longer than the library accepts: the document gets a status, the piece no tokens
+                const int64_t d = find_doc(w, pos);
+                if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
+                rec = HR_GAP << HR_KIND_SHIFT;
+            }
+        }
+        const bool queued = cls >= 0;
+        if (mine && !queued) w.hrec[(int64_t)strip * T + h] = rec;
+        add_strip_counts(w, strip, mine && !queued, cnt);
+#ifdef JTK_EXP_NOQUEUE                                                        // (timing experiment: results are wrong)
+        for (uint64_t todo = 0; todo;) {
+#else
+        for (uint64_t todo = __ballot(queued); todo;) {
+#endif
+            const int c = __builtin_amdgcn_readlane(cls, jtk_ctz64(todo));
+            const uint64_t mask = __ballot(cls == c);
+            todo &= ~mask;
+            uint32_t base = 0;
+            if (lane == jtk_ctz64(mask)) {
+                const uint32_t cn = (uint32_t)__popcll(mask);
+                base = c < JTK_NBINS ? atomicAdd(&s_qcount[c], cn) : atomicAdd(c == JTK_NBINS ? w.mid_count : c == JTK_NBINS + 1 ? w.long_count : w.n_giant, cn);
+            }
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, jtk_ctz64(mask));
+            if (cls == c) {
+                const uint32_t i = base + mbcnt64(mask);
+                if (c < JTK_NBINS) {
+                    const uint64_t meta = (uint64_t)pos | ((uint64_t)(plen - 1) << JTK_QE_LEN_SHIFT);
+                    w.qe[c][(int64_t)blockIdx.x * w.q_cap[c] + i] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), h, 0u);
+                } else (c == JTK_NBINS ? w.mid_list : c == JTK_NBINS + 1 ? w.long_list : w.giant_list)[i] = JtkLongPiece{pos, (int32_t)plen, h};
+            }
+        }
         ho_head += nl;
         wave_lds_fence();
         STAMP_END(3);
@@ -426,11 +327,8 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
             if (lane == (kc >> 6)) hw = bo;
             STAMP_END(1);
             STAMP_ADD(4, 1);
-            // 64 holes wait: a batch (and before it a merge round, if the hard ring could not take the batch's pieces)
-            if (ho_tail - ho_head >= 64u) {
-                if (hd_tail - hd_head >= 64u) merge_round(64u);
-                hole_batch(64u);
-            }
+            // 64 holes wait: a batch
+            if (ho_tail - ho_head >= 64u) hole_batch(64u);
         }
         asm volatile("" ::"v"(touch));
         // the strip's hole bitmap (one word per chunk) and its dense tokens' count
@@ -441,11 +339,10 @@ __global__ void __launch_bounds__(ENC_THREADS) k_strip_encode(JtkWork w, JtkDevi
         STAMP_ADD(12, nholes);
     }
     // ---- the wave's last holes and hard pieces
-    while (ho_tail != ho_head) {
-        if (hd_tail - hd_head >= 64u) merge_round(64u);
-        hole_batch(min(64u, ho_tail - ho_head));
-    }
-    while (hd_tail != hd_head) merge_round(min(64u, hd_tail - hd_head));
+    while (ho_tail != ho_head) hole_batch(min(64u, ho_tail - ho_head));
+    // how many entries this workgroup's queues hold
+    __syncthreads();
+    if (tid < JTK_NBINS) w.q_count[tid * w.n_shards + blockIdx.x] = s_qcount[tid];
 #ifdef JTK_ENC_STAMP
     st_acc[0] = __builtin_amdgcn_s_memtime() - st_wave0;
     if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_enc_stamp[i], (unsigned long long)st_acc[i]);

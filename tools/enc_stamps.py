@@ -39,7 +39,7 @@ def main():
         v = [int(x) for x in buf]
         tot, main, mrg, hol = v[0], v[1], v[2], v[3]
         strips, pieces = max(1, v[8]), v[9]
-        print("%-20s strip_encode %.3f ms expand %.3f ms | wave time: main %.0f%% hole batches %.0f%% merge %.0f%% other %.0f%% | per strip: %.0f pieces, %.0f holes (%.0f%%), "
+        print("%-20s strip_encode %.3f ms expand %.3f ms | wave time: main %.0f%% hole batches %.0f%% (merge %.0f%%) other %.0f%% | per strip: %.0f pieces, %.0f holes (%.0f%%), "
               "%.1f chunks, %.2f batches (%.0f%% of lanes), %.2f rounds (%.0f%% of lanes), %.0f memo hits, %.0f kcycles" % (
                   name, b.kernel_times()["strip_encode"], b.kernel_times()["strip_expand"], 100.0 * main / tot, 100.0 * hol / tot, 100.0 * mrg / tot,
                   100.0 * (tot - main - mrg - hol) / tot, pieces / strips, v[12] / strips, 100.0 * v[12] / max(1, pieces), v[4] / strips,
