@@ -72,7 +72,7 @@ struct ChunkSet {
     hipEvent_t ev_scan = nullptr;    // this set's tile_scan has run (the next chunk's scan waits for it: token order)
     hipEvent_t ev_done = nullptr;    // this set's last kernel has run
     DevBuf zeroed;                   // docmask | list counters | queue counters
-    DevBuf piecemask, gapmask, stok, hrec, holebits, htok, docpre, tile_tot, tile_off, queues, mid_list, long_list, giant_list;
+    DevBuf piecemask, gapmask, stok, hrec, htok, docpre, tile_tot, tile_off, queues, mid_list, long_list, giant_list;
     JtkWork work{};
     bool used = false;               // by the current job
 };
@@ -307,7 +307,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ChunkSet& cs : b->set) {
         if (cs.stream) (void)hipStreamSynchronize(cs.stream);
-        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.stok, &cs.hrec, &cs.holebits, &cs.htok, &cs.docpre, &cs.tile_tot, &cs.tile_off, &cs.queues,
+        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.stok, &cs.hrec, &cs.htok, &cs.docpre, &cs.tile_tot, &cs.tile_off, &cs.queues,
                           &cs.mid_list, &cs.long_list, &cs.giant_list};
         for (DevBuf* d : bufs) d->release();
         if (cs.ev_scan) (void)hipEventDestroy(cs.ev_scan);
@@ -393,6 +393,9 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t nt = (size_t)w.n_tiles;
     w.n_shards = (uint32_t)jtk_strip_encode_grid(w.n_tiles);
+    w.enc_waves = (uint32_t)jtk_strip_encode_waves();
+    const size_t n_regions = (size_t)w.n_shards * w.enc_waves;     // waves of k_strip_encode: each fills its own region of stok / hrec
+    w.wave_cap = (uint32_t)(((size_t)w.n_tiles + n_regions - 1) / n_regions * JTK_TILE);
     const size_t qcnt_bytes = JTK_NBINS * (size_t)JTK_MAX_Q_SHARDS * 4;
     const size_t tot_bytes = align_up(nt * 4, 16);                  // tile_tot: zeroed with the masks and counters
     const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes + tot_bytes;
@@ -401,13 +404,13 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     const size_t tps = (nt + w.n_shards - 1) / w.n_shards;          // strips per queue shard (= workgroup of k_strip_encode)
     const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4, JTK_BIN_CAP5, JTK_BIN_CAP6};
     size_t q_bytes = 0;
-    for (int k = 0; k < JTK_NBINS; k++) q_bytes += tps * caps[k] * w.n_shards * 16;
+    for (int k = 0; k < JTK_NBINS; k++) q_bytes += tps * caps[k] * w.n_shards * (k < JTK_NBINS_SHORT ? 32 : 16);
     int rc;
     if ((rc = cs.zeroed.ensure(zero_bytes)) || (rc = cs.piecemask.ensure(mask_bytes)) ||
-        (rc = cs.stok.ensure(nt * JTK_TILE * 4)) || (rc = cs.hrec.ensure(nt * JTK_TILE * 8)) || (rc = cs.holebits.ensure(nt * 64 * 8)) ||
+        (rc = cs.stok.ensure(n_regions * w.wave_cap * 4 + 64)) || (rc = cs.hrec.ensure(n_regions * w.wave_cap * 8 + 64)) ||
         (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
         (rc = cs.docpre.ensure(nt * JTK_TILE * 4 + 64)) ||
-        (rc = cs.tile_tot.ensure(align_up(nt * 4, 16) + 16)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
+        (rc = cs.tile_tot.ensure(align_up(nt * 4, 16) * 2 + 16)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
         (rc = cs.queues.ensure(q_bytes)) ||
         (rc = cs.mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
@@ -425,15 +428,15 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.docpre = (uint32_t*)cs.docpre.p;
     w.tile_tot = (uint32_t*)(z + mask_bytes + 32 + qcnt_bytes);
     w.tile_np = (uint32_t*)cs.tile_tot.p;
+    w.sbase = (uint32_t*)((uint8_t*)cs.tile_tot.p + align_up(nt * 4, 16));
     w.hrec = (uint64_t*)cs.hrec.p;
-    w.holebits = (uint64_t*)cs.holebits.p;
     w.tile_off = (int64_t*)cs.tile_off.p;
     {
         uint8_t* qp = (uint8_t*)cs.queues.p;
         for (int k = 0; k < JTK_NBINS; k++) {
             w.qe[k] = (uint4*)qp;
             w.q_cap[k] = (int64_t)(tps * caps[k]);
-            qp += tps * caps[k] * w.n_shards * 16;
+            qp += tps * caps[k] * w.n_shards * (k < JTK_NBINS_SHORT ? 32 : 16);
         }
     }
     w.mid_list = (JtkLongPiece*)cs.mid_list.p;

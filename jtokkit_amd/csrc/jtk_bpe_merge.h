@@ -15,16 +15,15 @@ __device__ __forceinline__ void short_bin(const JtkWork& w, const JtkDeviceTable
     const int shard = blockIdx.x % w.n_shards;
     uint32_t* const id = L.id + tid;
     uint32_t* const rk = L.rk + tid;
-    const uint4* const qe = w.qe[BIN] + (int64_t)shard * w.q_cap[BIN];
+    const uint4* const qe = w.qe[BIN] + (int64_t)shard * w.q_cap[BIN] * 2;       // 32-byte entries: position, length, hole number | the bytes
     for (uint32_t base = kq * THREADS; base < count; base += K * THREADS) {
         const uint32_t qi = base + (uint32_t)tid;
         const bool have = qi < count;
-        uint4 ent = make_uint4(0, 0, 0, 0);
-        if (have) ent = qe[qi];
+        uint4 ent = make_uint4(0, 0, 0, 0), tx = make_uint4(0, 0, 0, 0);
+        if (have) { ent = qe[2 * (size_t)qi]; tx = qe[2 * (size_t)qi + 1]; }
         const uint64_t meta = ((uint64_t)ent.y << 32) | ent.x;
         const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
         const int len = have ? (int)((meta >> JTK_QE_LEN_SHIFT) & 31u) + 1 : 0;
-        const uint4 tx = load_text16(w.text, pos, w.n_bytes);
         const uint32_t d4[4] = {tx.x, tx.y, tx.z, tx.w};
         uint32_t b[NS + 1];
 #pragma unroll
@@ -49,15 +48,12 @@ __device__ __forceinline__ void short_bin(const JtkWork& w, const JtkDeviceTable
                 for (uint32_t a = alive; a; a &= a - 1u) dst[i++] = id[(uint32_t)__builtin_ctz(a) * THREADS];
                 rec = (uint64_t)c | ((uint64_t)s << 21) | (HR_REF << HR_KIND_SHIFT);
             }
-            w.hrec[strip * T + ent.z] = rec;
+            put_hole(w, (int64_t)(((uint64_t)ent.w << 32) | ent.z), c, rec);
         }
         if (memo) {
             // remember the result under the piece's bytes (only the lane that claims an empty slot writes it)
             const uint32_t ulen = (uint32_t)len;
-            const uint64_t runm = ~0ull >> ((0u - 8u * ulen) & 63u);
-            const bool big = ulen > 8u;
-            const uint64_t mlo = big ? ~0ull : runm, mhi = big ? runm : 0ull;
-            const uint32_t key0 = tx.x & (uint32_t)mlo, key1 = tx.y & (uint32_t)(mlo >> 32), key2 = tx.z & (uint32_t)mhi, key3 = tx.w & (uint32_t)(mhi >> 32);
+            const uint32_t key0 = tx.x, key1 = tx.y, key2 = tx.z, key3 = tx.w;   // (zero beyond the piece's length: k_strip_encode masked them)
             if (have && c <= MEMO_MAX_TOKENS && key0 != 0u) {
                 const uint32_t mix = jtk_tok16_mix(key0, key1, key2, key3, ulen);
                 uint4* e = memo + (size_t)memo_slot(mix, w.memo_mask) * 2u;
@@ -146,7 +142,7 @@ __device__ __forceinline__ void lean_bin(const JtkWork& w, const JtkDeviceTables
                 m &= m - (M)1;
                 dst[idx++] = id[j * THREADS];
             }
-            w.hrec[(pos / T) * T + ent.z] = (uint64_t)c | ((uint64_t)(pos % T) << 21) | (HR_REF << HR_KIND_SHIFT);
+            put_hole(w, (int64_t)(((uint64_t)ent.w << 32) | ent.z), c, (uint64_t)c | ((uint64_t)(pos % T) << 21) | (HR_REF << HR_KIND_SHIFT));
         }
         add_strip_counts(w, (uint32_t)(pos / T), have, c);
     }
@@ -256,7 +252,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
     uint32_t qi = 0;
     int64_t pos = 0;
     int len = 0, tpart = 0;
-    uint32_t hole = 0;
+    uint64_t hole = 0;
     constexpr int NW = (SLOTS + 63) / 64;
     uint64_t alive[NW];
     mask_init<NW>(alive, 0);
@@ -324,7 +320,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
         // (4) consume
         if (st == ST_NEED) {
             const uint64_t entry = ((uint64_t)v0.y << 32) | v0.x;
-            hole = v0.z;
+            hole = ((uint64_t)v0.w << 32) | v0.z;
             pos = (int64_t)(entry & JTK_QE_POS_MASK);
             len = (int)((entry >> JTK_QE_LEN_SHIFT) & 255u) + 1;
             tpart = 0;
@@ -424,7 +420,7 @@ __device__ __forceinline__ void merge_bin(const JtkWork& w, const JtkDeviceTable
                         dst[idx++] = id[j * THREADS];
                     }
                 }
-                w.hrec[(pos / T) * T + hole] = (uint64_t)c | ((uint64_t)(pos % T) << 21) | (HR_REF << HR_KIND_SHIFT);
+                put_hole(w, (int64_t)hole, c, (uint64_t)c | ((uint64_t)(pos % T) << 21) | (HR_REF << HR_KIND_SHIFT));
                 atomicAdd(&w.tile_tot[pos / T], c);
                 st = ST_NEED;
             }
@@ -483,8 +479,8 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
     const uint32_t cnt = (CAP == JTK_MID_CAP) ? *w.mid_count : *w.long_count;
     for (uint32_t i = wave_id; i < cnt; i += n_waves) {
         const JtkLongPiece lp = list[i];
-        if (lp.len <= 0) continue;                                 // found by k_long_shortcut
-        const int len = lp.len;
+        const int len = (int)(lp.idx_len >> 40);
+        if (len <= 0) continue;                                    // found by k_long_shortcut
         for (int j = lane; j < len; j += WAVE) {
             const uint32_t b0 = w.text[lp.start + j];
             s_id[j] = t.byte_rank[b0];
@@ -503,7 +499,7 @@ __device__ __forceinline__ void merge_long(const JtkWork& w, const JtkDeviceTabl
             total += (uint32_t)__popcll(bal);
         }
         if (lane == 0) {
-            w.hrec[(lp.start / T) * T + lp.hole] = (uint64_t)total | ((uint64_t)(lp.start % T) << 21) | (HR_REF << HR_KIND_SHIFT);
+            put_hole(w, (int64_t)(lp.idx_len & ((1ull << 40) - 1ull)), total, (uint64_t)total | ((uint64_t)(lp.start % T) << 21) | (HR_REF << HR_KIND_SHIFT));
             atomicAdd(&w.tile_tot[lp.start / T], total);
         }
         wave_lds_fence();
@@ -539,8 +535,8 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
     constexpr int CH = JTK_GIANT_CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = blockDim.x, NWV = NT >> 6;
     const JtkLongPiece lp = w.giant_list[gi];
-    if (lp.len <= 0) return;                                      // found by k_long_shortcut (workgroup-uniform)
-    const int len = lp.len;
+    const int len = (int)(lp.idx_len >> 40);
+    if (len <= 0) return;                                         // found by k_long_shortcut (workgroup-uniform)
     uint32_t* gid = w.htok + lp.start;
     uint32_t* grk = w.docpre + lp.start;
     const int nch = (len + CH - 1) / CH;
@@ -622,7 +618,7 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
             total += (uint32_t)__popcll(bal);
         }
         if (lane == 0) {
-            w.hrec[(lp.start / T) * T + lp.hole] = (uint64_t)total | ((uint64_t)(lp.start % T) << 21) | (HR_REF << HR_KIND_SHIFT);
+            put_hole(w, (int64_t)(lp.idx_len & ((1ull << 40) - 1ull)), total, (uint64_t)total | ((uint64_t)(lp.start % T) << 21) | (HR_REF << HR_KIND_SHIFT));
             atomicAdd(&w.tile_tot[lp.start / T], total);
         }
     }
@@ -755,7 +751,7 @@ __global__ void __launch_bounds__(256) k_long_shortcut(JtkWork w, JtkDeviceTable
                 const int64_t pos = (int64_t)(meta & JTK_QE_POS_MASK);
                 const uint32_t id = long_lookup(w, t, pos, (int64_t)((meta >> JTK_QE_LEN_SHIFT) & 255u) + 1);
                 if (id != JTK_RANK_NONE) {
-                    w.hrec[(pos / T) * T + ent.z] = (uint64_t)id | (HR_TOKS << HR_KIND_SHIFT);   // one token
+                    put_hole(w, (int64_t)(((uint64_t)ent.w << 32) | ent.z), 1u, (uint64_t)id | (HR_TOKS << HR_KIND_SHIFT));   // one token
                     atomicAdd(&w.tile_tot[pos / T], 1u);
                     qe[i].y = ent.y | 0x80000000u;                    // JTK_QE_DONE
                 }
@@ -767,11 +763,11 @@ __global__ void __launch_bounds__(256) k_long_shortcut(JtkWork w, JtkDeviceTable
         const uint32_t count = which == 0 ? *w.mid_count : which == 1 ? *w.long_count : *w.n_giant;
         for (uint32_t i = gtid; i < count; i += gn) {
             const JtkLongPiece lp = list[i];
-            const uint32_t id = long_lookup(w, t, lp.start, lp.len);
+            const uint32_t id = long_lookup(w, t, lp.start, (int64_t)(lp.idx_len >> 40));
             if (id != JTK_RANK_NONE) {
-                w.hrec[(lp.start / T) * T + lp.hole] = (uint64_t)id | (HR_TOKS << HR_KIND_SHIFT);   // one token
+                put_hole(w, (int64_t)(lp.idx_len & ((1ull << 40) - 1ull)), 1u, (uint64_t)id | (HR_TOKS << HR_KIND_SHIFT));   // one token
                 atomicAdd(&w.tile_tot[lp.start / T], 1u);
-                list[i].len = 0;
+                list[i].idx_len = lp.idx_len & ((1ull << 40) - 1ull);
             }
         }
     }

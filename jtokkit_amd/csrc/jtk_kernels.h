@@ -16,7 +16,7 @@
 // SHARD = workgroup of k_strip_encode (which claims its entries with an atomic in LDS: no global atomic on this path -- a
 // few counters shared by the whole grid took 1 ns per claim, 5 ms per GiB of mixed text).  An entry is 16 bytes:
 //   x, y  pos (37 bits) | (len - 1) << 37   (JTK_QE_DONE: found by k_long_shortcut, nothing left to merge)
-//   z     hole number of the piece in its strip (where its record goes: hrec[strip * JTK_TILE + z])
+//   z, w  index of the piece's slot and hole record (stok / hrec)
 // Bins 0..2 are pieces of up to JTK_SHORT_MAX bytes that are no table entry (the whole-piece lookup was made by
 // k_strip_encode), bins 3..6 longer ones (for which the rank table's entries of more than 16 bytes are found by merging).
 #define JTK_SHORT_MAX 16
@@ -67,8 +67,7 @@ struct JtkDeviceTables {
 
 struct JtkLongPiece {       // a piece of more than JTK_BIN_MAXLEN bytes
     int64_t start;
-    int32_t len;            // (0: found by k_long_shortcut)
-    uint32_t hole;          // its hole number in its strip
+    uint64_t idx_len;       // index of its slot and hole record (40 bits) | length << 40   (length 0: found by k_long_shortcut)
 };
 
 struct JtkResult {          // of a whole batch (all its chunks)
@@ -98,11 +97,13 @@ struct JtkWork {
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)
     uint64_t* gapmask;      // NULL, or (caller-supplied pieces, jtk_batch_encode_pieces) bit p: the "piece" that starts at byte p is
                             // text between two matches of the caller's pattern: it is not encoded (matcher.find() skips it)
-    uint32_t* stok;         // [n_tiles * JTK_TILE] the tokens of each strip's DENSE pieces (<= 8 bytes, found in their primary tok8
-                            // slot), in order, packed from the strip's first word
-    uint64_t* holebits;     // [n_tiles * 64] per strip and chunk of 64 pieces: bit j: piece j of the chunk is a hole (anything else)
+    uint32_t* stok;         // [n_tiles * JTK_TILE] per strip, one slot per piece in text order: the token of a DENSE piece (<= 8 bytes,
+                            // found in its primary tok8 slot), or SLOT_HOLE
     uint64_t* hrec;         // [n_tiles * JTK_TILE] per strip, by hole number: the hole's tokens (HR_* in jtk_strip_encode.h)
     uint32_t* tile_np;      // [n_tiles] pieces of the strip
+    uint32_t* sbase;        // [n_tiles] where the strip's slots start in its wave's region of stok / hrec (jtk_strip_common.h)
+    uint32_t wave_cap;      // indices per wave region
+    uint32_t enc_waves;     // waves per workgroup of k_strip_encode
     uint4* memo;            // NULL, or [8 XCDs][memo_mask + 1][2]: merged pieces remembered for the rest of the job (jtk_strip_encode.h)
     uint32_t memo_mask;
     uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece that became more than three tokens, packed from the
@@ -174,6 +175,7 @@ void jtk_launch_mark_pieces(const JtkWork& w, const int64_t* begin, const int64_
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 int jtk_strip_encode_grid(int64_t n_tiles);                                                   // workgroups of k_strip_encode = queue shards
+int jtk_strip_encode_waves(void);                                                             // waves per workgroup
 void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // every strip: dense tokens, hole bitmap, hole records; queues
 void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);     // only if t.longtok.n
 void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);         // the queued pieces' hole records

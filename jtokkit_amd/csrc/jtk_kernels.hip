@@ -581,6 +581,7 @@ int jtk_strip_encode_grid(int64_t n_tiles) {
     int64_t wgs = n_tiles < full * ENC_WAVES ? (n_tiles < full ? n_tiles : full) : full;   // few strips: one wave each on as many CUs as possible
     return (int)(wgs < 1 ? 1 : wgs);
 }
+int jtk_strip_encode_waves(void) { return ENC_WAVES; }
 void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s) {
     hipLaunchKernelGGL(k_strip_encode, dim3(w.n_shards), dim3(ENC_THREADS), 0, s, w, t);
 }
@@ -609,6 +610,11 @@ extern "C" int jtk_debug_stamps(unsigned long long* out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_enc_stamp), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[16] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_enc_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+extern "C" int jtk_debug_stamps_expand(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_exp_stamp), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
 

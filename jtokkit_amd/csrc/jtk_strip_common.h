@@ -17,6 +17,23 @@ __device__ __forceinline__ uint32_t mbcnt64_(uint64_t m) {          // set bits 
 }
 
 
+// Where the strips' slots and hole records live.  stok (4 B) and hrec (8 B) are indexed alike: one index per piece.  A wave of
+// k_strip_encode owns a REGION of that index space (wave_cap indices: enough for the worst case of all its strips) and fills
+// it densely, strip after strip, each strip's pieces in order (sbase[strip]: where the strip starts in its wave's region).
+// Worst-case regions per STRIP (4096 indices each, a few hundred used) were tried first: the sparse footprint -- 16 and 32 KB
+// strides -- made every memory instruction of the expand kernel several times slower than its bytes explain.
+__device__ __forceinline__ int64_t strip_region(const JtkWork& w, int64_t strip) {
+    const int64_t g = w.n_shards;
+    return ((strip % g) * w.enc_waves + (strip / g) % w.enc_waves) * (int64_t)w.wave_cap;
+}
+
+// A strip's slot stream (stok) holds one 32-bit slot per piece, in text order:
+//   a token id            the piece's one token (a dense piece, or a hole that turned out to be one token)
+//   SLOT_HOLE             placeholder of a hole whose result is not in yet (none is left when k_strip_expand runs)
+//   SLOT_MULTI | count    a hole with `count` tokens (0: none): they are in its hole record, hrec[the slot's index]
+constexpr uint32_t SLOT_HOLE = 0xFFFFFFFFu;
+constexpr uint32_t SLOT_MULTI = 0x80000000u;
+
 // hole record (8 bytes)
 constexpr int HR_KIND_SHIFT = 53;              // bits 53..54
 constexpr uint64_t HR_TOKS = 0;                // bits 0..50: up to three token ids, 17 bits each; bits 51..52: count - 1
@@ -42,6 +59,13 @@ __device__ __forceinline__ uint32_t xcc_id() {
 }
 __device__ __forceinline__ uint32_t memo_slot(uint32_t mix, uint32_t mask) { return (jtk_pair_mix2(mix) ^ (mix >> 9)) & mask; }
 __device__ __forceinline__ uint32_t memo_tag(uint32_t mix) { return ((mix >> 17) & 0x1FFFu) | 1u; }
+
+// the result of the hole at index `idx`: its slot, and its record unless it is a single token
+__device__ __forceinline__ void put_hole(const JtkWork& w, int64_t idx, uint32_t cnt, uint64_t rec) {
+    const bool one = cnt == 1u && ((rec >> HR_KIND_SHIFT) & 3ull) == HR_TOKS;
+    w.stok[idx] = one ? (uint32_t)rec & JTK_HT_ID_MASK : SLOT_MULTI | cnt;
+    if (!one && cnt) w.hrec[idx] = rec;
+}
 
 struct __attribute__((packed, aligned(1))) U4Bytes { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U2Bytes { uint32_t x, y; };

@@ -31,11 +31,18 @@
 #endif
 constexpr int ENC_WAVES = JTK_ENC_WAVES, ENC_THREADS = 64 * ENC_WAVES, ENC_WGS_PER_CU = JTK_ENC_WGS_PER_CU;
 constexpr int ENC_WIN = 512;                   // piece starts listed in LDS at a time
-constexpr int ENC_PEND = 128;                  // ring of pending holes / hard pieces (at most 127 wait)
+#ifndef JTK_ENC_G
+#define JTK_ENC_G 2
+#endif
+constexpr int ENC_G = JTK_ENC_G;               // chunks per step of the main path (loads in flight per lane)
+constexpr int ENC_PEND = 256;                  // ring of pending holes (at most 63 + 64 ENC_G wait)
+static_assert(63 + 64 * ENC_G < ENC_PEND && ENC_WIN % (64 * ENC_G) == 0, "pending ring / window");
 static_assert(T == 4096, "a strip is 64 mask words: one per lane");
 
 struct __attribute__((aligned(16))) EncWaveLds {
-    uint2 holes[ENC_PEND];                     // pending holes:  x = offset (12) | (min(len, 17) - 1) << 12 | hole number << 17, y = strip
+    uint32_t ho_sl[ENC_PEND];                  // pending holes: offset in the strip (12) | (min(len, 17) - 1) << 12,
+    uint32_t ho_strip[ENC_PEND];               //                their strip,
+    uint32_t ho_idx[ENC_PEND];                 //                their index in the wave's region of stok / hrec
     uint16_t starts[ENC_WIN + 8];              // byte offsets of pieces k0 .. k0 + ENC_WIN (one more: where the last ends)
 };
 
@@ -80,6 +87,8 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
 #endif
     uint4* const memo = w.memo ? w.memo + (size_t)xcc_id() * ((size_t)w.memo_mask + 1u) * 2u : nullptr;   // this XCD's table
     uint32_t ho_head = 0, ho_tail = 0;            // pending holes  [head, tail)   (wave-uniform)
+    const int64_t region0 = ((int64_t)blockIdx.x * ENC_WAVES + wv) * (int64_t)w.wave_cap;   // this wave's region of stok / hrec
+    uint32_t cursor = 0;                          // ... filled so far
 
     // ---- one hole batch: a lane per pending hole -- everything the main path does not do
     auto hole_batch = [&](uint32_t nl) {
@@ -92,9 +101,11 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
         STAMP_ADD(11, nl);
         wave_lds_fence();
         const bool mine = (uint32_t)lane < nl;
-        const uint2 pe = W.holes[(ho_head + (uint32_t)lane) & (ENC_PEND - 1)];
-        const uint32_t strip = pe.y, s = pe.x & 0xFFFu, h = pe.x >> 17;
-        const uint32_t lenc = mine ? ((pe.x >> 12) & 31u) + 1u : 0u;             // 17: more than 16 bytes
+        const uint32_t ri = (ho_head + (uint32_t)lane) & (ENC_PEND - 1);
+        const uint32_t pe_x = W.ho_sl[ri], strip = W.ho_strip[ri];
+        const int64_t h = region0 + W.ho_idx[ri];                               // index of the hole's slot and record
+        const uint32_t s = pe_x & 0xFFFu;
+        const uint32_t lenc = mine ? ((pe_x >> 12) & 31u) + 1u : 0u;             // 17: more than 16 bytes
         const int64_t pos = mine ? (int64_t)strip * T + s : 0;
         const bool shortp = lenc <= (uint32_t)JTK_SHORT_MAX;
         const uint32_t len = shortp ? lenc : 0u;
@@ -208,7 +219,7 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
             }
         }
         const bool queued = cls >= 0;
-        if (mine && !queued) w.hrec[(int64_t)strip * T + h] = rec;
+        if (mine && !queued) put_hole(w, h, cnt, rec);
         add_strip_counts(w, strip, mine && !queued, cnt);
 #ifdef JTK_EXP_NOQUEUE                                                        // (timing experiment: results are wrong)
         for (uint64_t todo = 0; todo;) {
@@ -228,8 +239,14 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
                 const uint32_t i = base + mbcnt64(mask);
                 if (c < JTK_NBINS) {
                     const uint64_t meta = (uint64_t)pos | ((uint64_t)(plen - 1) << JTK_QE_LEN_SHIFT);
-                    w.qe[c][(int64_t)blockIdx.x * w.q_cap[c] + i] = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), h, 0u);
-                } else (c == JTK_NBINS ? w.mid_list : c == JTK_NBINS + 1 ? w.long_list : w.giant_list)[i] = JtkLongPiece{pos, (int32_t)plen, h};
+                    const uint4 ent = make_uint4((uint32_t)meta, (uint32_t)(meta >> 32), (uint32_t)h, (uint32_t)(h >> 32));
+                    if (c < JTK_NBINS_SHORT) {
+                        // (the short bins' entries carry the piece's bytes: the merge kernel reads dense 32-byte entries, not the text)
+                        uint4* e = w.qe[c] + ((int64_t)blockIdx.x * w.q_cap[c] + i) * 2;
+                        e[0] = ent;
+                        e[1] = make_uint4(key0, key1, key2, key3);
+                    } else w.qe[c][(int64_t)blockIdx.x * w.q_cap[c] + i] = ent;
+                } else (c == JTK_NBINS ? w.mid_list : c == JTK_NBINS + 1 ? w.long_list : w.giant_list)[i] = JtkLongPiece{pos, (uint64_t)h | ((uint64_t)plen << 40)};
             }
         }
         ho_head += nl;
@@ -245,12 +262,18 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
         if (wd * 64 + 63 >= n) pm &= (wd * 64 >= n) ? 0ull : ((1ull << (n - wd * 64)) - 1ull);
         const uint64_t gm = (gaps && wd < w.n_words) ? w.gapmask[wd] : 0ull;    // custom patterns: text no match covers
         // (touch the strip's text -- one word of every 64-byte block -- so that it is on its way while the masks are scanned)
+#ifdef JTK_EXP_NOTOUCH
+        const uint32_t touch = 0;
+#else
         const uint32_t touch = (B + lane * 64 < n) ? *reinterpret_cast<const uint32_t*>(w.text + B + lane * 64) : 0u;
+#endif
         const uint32_t cnt = (uint32_t)__popcll(pm);
         const uint32_t inc = wave_incl_scan_dpp(cnt);
         const int np = (int)(uint32_t)__shfl((int)inc, 63);
         const uint32_t pre = inc - cnt;
-        if (lane == 0) w.tile_np[strip] = (uint32_t)np;
+        const uint32_t sb = cursor;                                      // this strip's slots: region0 + sb ..
+        cursor += ((uint32_t)np + 3u) & ~3u;
+        if (lane == 0) { w.tile_np[strip] = (uint32_t)np; w.sbase[strip] = sb; }
         if (np == 0) continue;                                           // a strip inside one long piece
         // where the strip's last piece ends, relative to B: the end sentinel or the next strip's first piece (only "more
         // than 16 bytes away" matters beyond that: such a piece was merged by k_bpe_merge, its length is not needed here)
@@ -264,14 +287,11 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
             end_rel = some ? (uint32_t)(T + first * 64 + jtk_ctz64(fw)) : (uint32_t)(2 * T);
             if (n - B < T) end_rel = (uint32_t)(n - B);                      // the sentinel is inside this strip
         }
-        uint32_t* const out = w.stok + B;
         uint32_t run = 0;                                                // dense tokens of the strip so far
-        uint32_t nholes = 0;
-        uint64_t hw = 0;                                                 // lane c: the hole mask of chunk c
         const bool tail_strip = B + T + 16 > n;                          // (the last strips of the text: careful loads)
         int k0 = -ENC_WIN;
 
-        for (int kc = 0; kc < np; kc += 64) {
+        for (int kc = 0; kc < np; kc += 64 * ENC_G) {
             STAMP_BEGIN();
             if (kc >= k0 + ENC_WIN) {
                 // list the starts of pieces k0 .. k0 + ENC_WIN (each lane: the set bits of its word)
@@ -285,58 +305,75 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
                 if (lane == 0 && np - k0 <= ENC_WIN) W.starts[np - k0] = (uint16_t)end_rel;
                 wave_lds_fence();
             }
-            const int k = kc + lane;
-            const bool have = k < np;
-            const int rel = have ? k - k0 : 0;
-            const uint32_t s = W.starts[rel], e = W.starts[rel + 1];
-            const uint32_t plen = e - s;
-            // a piece of <= 8 bytes and its primary slot in the tok8 table
-            uint32_t tx0, tx1;
+            // ENC_G chunks per step: their text loads are in flight together, then their table probes (what bounds this path is
+            // the latency of those two dependent loads, not their number)
+            bool have[ENC_G], small[ENC_G];
+            uint32_t s[ENC_G], plen[ENC_G], tx0[ENC_G], tx1[ENC_G], key0[ENC_G], key1[ENC_G], len[ENC_G];
+            uint4 ka[ENC_G];
+#pragma unroll
+            for (int q = 0; q < ENC_G; q++) {
+                const int k = kc + 64 * q + lane;
+                have[q] = k < np;
+                const int rel = have[q] ? k - k0 : 0;
+                const uint32_t e = W.starts[rel + 1];
+                s[q] = W.starts[rel];
+                plen[q] = e - s[q];
+            }
             if (!tail_strip) {
-                const U2Bytes v = *reinterpret_cast<const U2Bytes*>(w.text + B + s);
-                tx0 = v.x; tx1 = v.y;
-            } else {
-                const uint4 v = load_text16(w.text, B + s, n);
-                tx0 = v.x; tx1 = v.y;
-            }
-            const bool small = have && plen <= 8u;
-            const uint32_t len = small ? plen : 0u;
-            const uint64_t runm = ~0ull >> ((0u - 8u * len) & 63u);              // 8 len ones
-            const uint32_t key0 = tx0 & (uint32_t)runm, key1 = tx1 & (uint32_t)(runm >> 32);
-            const uint32_t mix = jtk_tok16_mix(key0, key1, 0u, 0u, len);
-            const uint4 ka = *reinterpret_cast<const uint4*>(tok + ((size_t)jtk_reduce32(mix, n8) << 4));   // lo, hi, id, len
-            bool hit = small && ((ka.x ^ key0) | (ka.y ^ key1) | ((ka.w & JTK_TOK_LEN_MASK) ^ len)) == 0u;
-            if (gaps) {                                                          // (wave-uniform; the shuffles are evaluated by all lanes)
-                const uint32_t glo = (uint32_t)__shfl((int)(uint32_t)gm, (int)(s >> 6)), ghi = (uint32_t)__shfl((int)(uint32_t)(gm >> 32), (int)(s >> 6));
-                if ((((s & 32u) ? ghi : glo) >> (s & 31u)) & 1u) hit = false;    // unmatched text is a hole without tokens
-            }
-            // dense pieces: the token, in order
-            const uint64_t bh = __ballot(hit);
-            if (hit && !w.count_only) out[run + mbcnt64(bh)] = ka.z;
-            run += (uint32_t)__popcll(bh);
-            // holes: a bit in the strip's bitmap and an entry in the pending ring
-            const uint64_t bo = __ballot(have && !hit);
-            if (bo) {
-                if (have && !hit) {
-                    const uint32_t hno = nholes + mbcnt64(bo);
-                    W.holes[(ho_tail + mbcnt64(bo)) & (ENC_PEND - 1)] = make_uint2(s | ((min(plen, 17u) - 1u) << 12) | (hno << 17), (uint32_t)strip);
+#pragma unroll
+                for (int q = 0; q < ENC_G; q++) {
+                    const U2Bytes v = *reinterpret_cast<const U2Bytes*>(w.text + B + s[q]);
+                    tx0[q] = v.x; tx1[q] = v.y;
                 }
-                ho_tail += (uint32_t)__popcll(bo);
-                nholes += (uint32_t)__popcll(bo);
+            } else {
+#pragma unroll
+                for (int q = 0; q < ENC_G; q++) {
+                    const uint4 v = load_text16(w.text, B + s[q], n);
+                    tx0[q] = v.x; tx1[q] = v.y;
+                }
             }
-            if (lane == (kc >> 6)) hw = bo;
+            // a piece of <= 8 bytes and its primary slot in the tok8 table
+#pragma unroll
+            for (int q = 0; q < ENC_G; q++) {
+                small[q] = have[q] && plen[q] <= 8u;
+                len[q] = small[q] ? plen[q] : 0u;
+                const uint64_t runm = ~0ull >> ((0u - 8u * len[q]) & 63u);       // 8 len ones
+                key0[q] = tx0[q] & (uint32_t)runm; key1[q] = tx1[q] & (uint32_t)(runm >> 32);
+                const uint32_t mix = jtk_tok16_mix(key0[q], key1[q], 0u, 0u, len[q]);
+                ka[q] = *reinterpret_cast<const uint4*>(tok + ((size_t)jtk_reduce32(mix, n8) << 4));   // lo, hi, id, len
+            }
+#pragma unroll
+            for (int q = 0; q < ENC_G; q++) {
+                bool hit = small[q] && ((ka[q].x ^ key0[q]) | (ka[q].y ^ key1[q]) | ((ka[q].w & JTK_TOK_LEN_MASK) ^ len[q])) == 0u;
+                if (gaps) {                                                      // (wave-uniform; the shuffles are evaluated by all lanes)
+                    const uint32_t glo = (uint32_t)__shfl((int)(uint32_t)gm, (int)(s[q] >> 6)), ghi = (uint32_t)__shfl((int)(uint32_t)(gm >> 32), (int)(s[q] >> 6));
+                    if ((((s[q] & 32u) ? ghi : glo) >> (s[q] & 31u)) & 1u) hit = false;   // unmatched text is a hole without tokens
+                }
+                // one slot per piece, in order: the token of a dense piece, SLOT_HOLE for the others
+                if (have[q]) w.stok[region0 + sb + (uint32_t)(kc + 64 * q + lane)] = hit ? ka[q].z : SLOT_HOLE;
+                run += (uint32_t)__popcll(__ballot(hit));
+                // holes: a bit in the strip's bitmap and an entry in the pending ring
+                const uint64_t bo = __ballot(have[q] && !hit);
+                if (bo) {
+                    if (have[q] && !hit) {
+                        const uint32_t ri = (ho_tail + mbcnt64(bo)) & (ENC_PEND - 1);
+                        W.ho_sl[ri] = s[q] | ((min(plen[q], 17u) - 1u) << 12);
+                        W.ho_strip[ri] = (uint32_t)strip;
+                        W.ho_idx[ri] = sb + (uint32_t)(kc + 64 * q + lane);
+                    }
+                    ho_tail += (uint32_t)__popcll(bo);
+                }
+            }
             STAMP_END(1);
-            STAMP_ADD(4, 1);
+            STAMP_ADD(4, ENC_G);
             // 64 holes wait: a batch
-            if (ho_tail - ho_head >= 64u) hole_batch(64u);
+            while (ho_tail - ho_head >= 64u) hole_batch(64u);
         }
         asm volatile("" ::"v"(touch));
-        // the strip's hole bitmap (one word per chunk) and its dense tokens' count
-        if (lane < ((np + 63) >> 6)) w.holebits[strip * 64 + lane] = hw;
+        // the strip's dense pieces' tokens
         if (lane == 0 && run) atomicAdd(&w.tile_tot[strip], run);
         STAMP_ADD(8, 1);
         STAMP_ADD(9, np);
-        STAMP_ADD(12, nholes);
     }
     // ---- the wave's last holes and hard pieces
     while (ho_tail != ho_head) hole_batch(min(64u, ho_tail - ho_head));
@@ -356,9 +393,19 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
 // at every document's first byte, the tokens of its strip before it (docpre) for k_doc_offsets.
 // ---------------------------------------------------------------------------------------------------
 constexpr int EXPAND_THREADS = 256;
+constexpr int EXPAND_STAGE = 1024;             // tokens of a step (256 pieces) assembled in LDS; a step with more stores them directly
 
+#ifdef JTK_ENC_STAMP
+__device__ unsigned long long g_exp_stamp[16];
+#endif
 __global__ void __launch_bounds__(EXPAND_THREADS) k_strip_expand(JtkWork w) {
+    __shared__ uint32_t s_stage[EXPAND_THREADS / 64][EXPAND_STAGE];
+    uint32_t* const stage = s_stage[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
+#ifdef JTK_ENC_STAMP
+    uint64_t st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t st_wave0 = __builtin_amdgcn_s_memtime();
+#endif
     const int64_t strip = (int64_t)blockIdx.x * (EXPAND_THREADS / 64) + (threadIdx.x >> 6);
     if (strip >= w.n_tiles) return;
     const uint32_t total = w.tile_tot[strip];
@@ -386,12 +433,7 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_strip_expand(JtkWork w) {
     } else base = w.tile_off[strip];
     if (np == 0) return;
     const int64_t B = strip * T;
-    const int nchunks = (np + 63) >> 6;
     const bool store = w.count_only == 0;
-    // lane c: the hole mask of chunk c and the holes before it
-    const uint64_t hw = lane < nchunks ? w.holebits[strip * 64 + lane] : 0ull;
-    const uint32_t hc = (uint32_t)__popcll(hw);
-    const uint32_t hpre = wave_incl_scan_dpp(hc) - hc;
     // document starts in this strip (each is a piece start): lane L keeps those of its mask word, with the pieces before the word
     const int64_t wd = (B >> 6) + lane;
     const uint64_t dm = (wd < w.n_words) ? w.docmask[wd] : 0ull;
@@ -406,56 +448,113 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_strip_expand(JtkWork w) {
     }
     const uint64_t dmp = dm & pm;                                        // (a document start that is no piece start here: the end sentinel)
     const uint32_t pcnt = (uint32_t)__popcll(pm);
-    const uint32_t* const dense = w.stok + B;
-    const uint64_t* const hrec = w.hrec + B;
     uint32_t* const dst = reinterpret_cast<uint32_t*>(w.tokens) + base;
-    uint32_t run = 0;
-    for (int c = 0; c < nchunks; c++) {
-        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hw, c), whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hw >> 32), c);
-        const uint64_t word = ((uint64_t)whi << 32) | wlo;
-        const uint32_t hb = (uint32_t)__builtin_amdgcn_readlane((int)hpre, c);
-        const int k = c * 64 + lane;
-        const bool valid = k < np;
-        const bool ishole = ((word >> lane) & 1ull) != 0;                 // (bits of a chunk's mask beyond np are clear)
-        const uint32_t dbase = (uint32_t)(c * 64) - hb;                     // dense pieces before this chunk
-        uint32_t pos;
-        if (word == 0) {
-            // every piece a dense one: one token each
-            pos = run + (uint32_t)lane;
-            if (valid && store) dst[pos] = dense[dbase + (uint32_t)lane];
-            run += (uint32_t)min(64, np - c * 64);
+    uint32_t run = 0;                                                    // tokens placed
+#ifdef JTK_ENC_STAMP
+    st_acc[1] = __builtin_amdgcn_s_memtime() - st_wave0;
+#endif
+    // FOUR consecutive pieces per lane, 256 per step: one 16-byte load of their slots per lane (the kernel is a stream: what
+    // bounds it is the bytes in flight) and one wave scan of the lanes' token counts -- a slot says how many tokens its piece
+    // has, so nothing else has to be read before the places are known; only a hole of several tokens reads its record, at
+    // the slot's own index.  Everything is requested ahead: the slots two steps, the records (whose lanes the slots tell)
+    // one step -- all record loads of a step back to back, without branches (a lane without such a hole reads the strip's
+    // first record): with a branch around each load the compiler waited for every one of them in turn.
+    const int64_t idx0 = strip_region(w, strip) + w.sbase[strip];        // the strip's slots and hole records: idx0 + piece number
+    auto slots_of = [&](int k0) { return k0 + 4 * lane < np ? *reinterpret_cast<const uint4*>(w.stok + idx0 + k0 + 4 * lane) : make_uint4(0, 0, 0, 0); };
+    struct Step { uint32_t sl[4], cn[4], tot, nh; bool valid[4], ishole[4]; uint64_t rec[4]; };
+    auto prepare = [&](const uint4& v, int k0, Step& st) {
+        // the step's pieces from their slots, and its record loads
+        const int kb = k0 + 4 * lane;
+        st.sl[0] = v.x; st.sl[1] = v.y; st.sl[2] = v.z; st.sl[3] = v.w;
+        st.tot = 0; st.nh = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            st.valid[i] = kb + i < np;
+            st.ishole[i] = st.valid[i] && (st.sl[i] & SLOT_MULTI) != 0u;
+            st.cn[i] = st.valid[i] ? (st.ishole[i] ? (st.sl[i] == SLOT_HOLE ? 0u : st.sl[i] & ~SLOT_MULTI) : 1u) : 0u;
+            st.tot += st.cn[i];
+            st.nh += st.ishole[i] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) st.rec[i] = w.hrec[(st.ishole[i] && st.cn[i]) ? idx0 + kb + i : idx0];
+    };
+    uint4 v_nn = slots_of(256);
+    Step nx;
+    prepare(slots_of(0), 0, nx);
+    for (int k0 = 0; k0 < np; k0 += 256) {
+        STAMP_BEGIN();
+        STAMP_ADD(4, 1);
+        const Step st = nx;
+        const uint4 v_n = v_nn;
+        v_nn = slots_of(k0 + 512);
+        if (k0 + 256 < np) prepare(v_n, k0 + 256, nx);
+        const uint32_t (&sl)[4] = st.sl;
+        const uint32_t (&cn)[4] = st.cn;
+        const bool (&valid)[4] = st.valid;
+        const bool (&ishole)[4] = st.ishole;
+        const uint64_t (&rec)[4] = st.rec;
+        const uint32_t tot = st.tot, nh = st.nh;
+        const int kb = k0 + 4 * lane;
+        (void)kb;
+        uint32_t pos0;
+        if (!__ballot(nh != 0)) {
+            // every piece one token
+            pos0 = run + 4u * (uint32_t)lane;
+            run += (uint32_t)min(256, np - k0);
         } else {
-            const uint64_t vmask = (np - c * 64 >= 64) ? ~0ull : ((1ull << (np - c * 64)) - 1ull);
-            uint32_t tk = 0;
-            uint64_t rec = 0;
-            if (valid && !ishole) tk = dense[dbase + mbcnt64(~word & vmask)];
-            if (ishole) rec = hrec[hb + mbcnt64(word)];
-            const uint32_t kind = (uint32_t)(rec >> HR_KIND_SHIFT) & 3u;
-            uint32_t cn = valid ? 1u : 0u;
-            if (ishole) cn = kind == HR_TOKS ? (uint32_t)((rec >> 51) & 3u) + 1u : kind == HR_REF ? (uint32_t)(rec & 0x1FFFFFu) : 0u;
-            const uint32_t inc = wave_incl_scan_dpp(cn);
-            pos = run + inc - cn;
+            const uint32_t inc = wave_incl_scan_dpp(tot);
+            pos0 = run + inc - tot;
             run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            if (store) {
-                if (ishole && kind == HR_TOKS) tk = (uint32_t)rec & JTK_HT_ID_MASK;
-                const bool isref = ishole && kind == HR_REF;
-                if (cn && !isref) dst[pos] = tk;
-                if (ishole && kind == HR_TOKS && cn > 1u) {
-                    dst[pos + 1] = (uint32_t)(rec >> 17) & JTK_HT_ID_MASK;
-                    if (cn > 2u) dst[pos + 2] = (uint32_t)(rec >> 34) & JTK_HT_ID_MASK;
-                }
-                if (__ballot(isref)) {
-                    if (isref) {
-                        const uint32_t* src = w.htok + B + ((uint32_t)(rec >> 21) & 0xFFFu);
-                        for (uint32_t i = 0; i < cn; i++) dst[pos + i] = src[i] & JTK_HT_ID_MASK;
+        }
+        if (store) {
+            // The step's tokens are assembled in LDS and leave in full 256-byte stores: written from where they are computed
+            // they would be a dozen sparse store instructions per step, and the CU's memory pipeline -- every wave's loads
+            // queue behind them -- was what bounded the kernel (13 M write requests for 31 M tokens; 4 x slower).
+            const uint32_t step_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos0);      // (lane 0: the step's first token)
+            const uint32_t step_tot = run - step_base;
+            const bool staged = step_tot <= (uint32_t)EXPAND_STAGE;                               // (wave-uniform)
+            // place p of the strip: in the LDS stage (relative to the step's first token) or straight in the output
+            auto emit = [&](auto put) {
+                if (nh == 0) {
+                    if (valid[0]) put(pos0, sl[0]);
+                    if (valid[1]) put(pos0 + 1, sl[1]);
+                    if (valid[2]) put(pos0 + 2, sl[2]);
+                    if (valid[3]) put(pos0 + 3, sl[3]);
+                } else {
+                    uint32_t p = pos0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (!ishole[i]) { if (valid[i]) put(p, sl[i]); }
+                        else if (cn[i]) {
+                            const uint32_t kind = (uint32_t)(rec[i] >> HR_KIND_SHIFT) & 3u;
+                            if (kind == HR_TOKS) {
+                                put(p, (uint32_t)rec[i] & JTK_HT_ID_MASK);
+                                if (cn[i] > 1u) put(p + 1, (uint32_t)(rec[i] >> 17) & JTK_HT_ID_MASK);
+                                if (cn[i] > 2u) put(p + 2, (uint32_t)(rec[i] >> 34) & JTK_HT_ID_MASK);
+                            } else if (kind == HR_REF) {
+                                const uint32_t* src = w.htok + B + ((uint32_t)(rec[i] >> 21) & 0xFFFu);
+                                for (uint32_t j = 0; j < cn[i]; j++) put(p + j, src[j] & JTK_HT_ID_MASK);
+                            }
+                        }
+                        p += cn[i];
                     }
                 }
+            };
+            if (staged) emit([&](uint32_t p, uint32_t v) { stage[p - step_base] = v; });
+            else emit([&](uint32_t p, uint32_t v) { dst[p] = v; });
+            if (staged) {
+                wave_lds_fence();
+                for (uint32_t i = (uint32_t)lane; i < step_tot; i += 64u) dst[step_base + i] = stage[i];
+                wave_lds_fence();
             }
         }
+#ifdef JTK_ENC_STAMP
+        st_acc[3] += __builtin_amdgcn_s_memtime() - st_t0;
+#endif
         // document starts among these pieces: tokens of the strip before them (rare: one or two per strip)
         if (any_doc) {
-            // lanes whose mask word holds a document start at one of this chunk's pieces
-            for (uint64_t todo = __ballot(dmp != 0 && ppre < (uint32_t)(c * 64 + 64) && ppre + pcnt > (uint32_t)(c * 64)); todo; todo &= todo - 1) {
+            // lanes whose mask word holds a document start at one of this step's pieces
+            for (uint64_t todo = __ballot(dmp != 0 && ppre < (uint32_t)(k0 + 256) && ppre + pcnt > (uint32_t)k0); todo; todo &= todo - 1) {
                 const int L = jtk_ctz64(todo);
                 const uint64_t dL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dmp >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dmp, L);
                 const uint64_t pL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pm >> 32), L) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pm, L);
@@ -463,12 +562,21 @@ __global__ void __launch_bounds__(EXPAND_THREADS) k_strip_expand(JtkWork w) {
                 for (uint64_t d = dL; d; d &= d - 1) {
                     const int bit = jtk_ctz64(d);
                     const int kk = (int)(preL + (uint32_t)__popcll(pL & ((1ull << bit) - 1ull)));
-                    if (kk >= c * 64 && kk < c * 64 + 64) {
-                        const uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)pos, kk - c * 64);
+                    if (kk >= k0 && kk < k0 + 256) {
+                        const int ln = (kk - k0) >> 2, sub = (kk - k0) & 3;
+                        uint32_t pv = (uint32_t)__builtin_amdgcn_readlane((int)pos0, ln);
+                        if (sub > 0) pv += (uint32_t)__builtin_amdgcn_readlane((int)cn[0], ln);
+                        if (sub > 1) pv += (uint32_t)__builtin_amdgcn_readlane((int)cn[1], ln);
+                        if (sub > 2) pv += (uint32_t)__builtin_amdgcn_readlane((int)cn[2], ln);
                         if (lane == 0) w.docpre[B + L * 64 + bit] = pv;
                     }
                 }
             }
         }
     }
+#ifdef JTK_ENC_STAMP
+    st_acc[0] = __builtin_amdgcn_s_memtime() - st_wave0;
+    st_acc[5] = 1;
+    if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_exp_stamp[i], (unsigned long long)st_acc[i]);
+#endif
 }

@@ -21,6 +21,8 @@ def main():
     lib = _native.lib()
     lib.jtk_debug_stamps.restype = C.c_int
     lib.jtk_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
+    lib.jtk_debug_stamps_expand.restype = C.c_int
+    lib.jtk_debug_stamps_expand.argtypes = [C.POINTER(C.c_ulonglong)]
     enc = jtokkit_amd.get_encoding("cl100k_base", device=0)
     n_docs = args.mb * 1000000 // 4096
     buf = (C.c_ulonglong * 16)()
@@ -34,9 +36,14 @@ def main():
         b.set_profiling(True)
         b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(off) - 1, len(text), ordinary=False, sync=True)
         lib.jtk_debug_stamps(buf)
+        lib.jtk_debug_stamps_expand(buf)
         b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(off) - 1, len(text), ordinary=False, sync=True)
         lib.jtk_debug_stamps(buf)
         v = [int(x) for x in buf]
+        lib.jtk_debug_stamps_expand(buf)
+        x = [int(t) for t in buf]
+        print("   expand: per strip %.1f kcycles (prologue %.1f, record waits %.1f, steps to their stores %.1f), %.1f steps" % (
+            x[0] / max(1, x[5]) / 1e3, x[1] / max(1, x[5]) / 1e3, x[2] / max(1, x[5]) / 1e3, x[3] / max(1, x[5]) / 1e3, x[4] / max(1, x[5])))
         tot, main, mrg, hol = v[0], v[1], v[2], v[3]
         strips, pieces = max(1, v[8]), v[9]
         print("%-20s strip_encode %.3f ms expand %.3f ms | wave time: main %.0f%% hole batches %.0f%% (merge %.0f%%) other %.0f%% | per strip: %.0f pieces, %.0f holes (%.0f%%), "
