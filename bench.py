@@ -3,7 +3,7 @@
 
 One "step" = one pass of the whole hot path over one batch of synthetic documents that is already resident in HBM: ONE
 jtk_batch_encode_device call (inside it the batch is cut into chunks of whole documents that flow through the library's
-scratch sets on their own streams: mark_docs, pretok_split, strip_encode, bpe_merge, tile_scan, strip_expand, doc_offsets per
+scratch sets on their own streams: mark_docs, pretok_split, piece_resolve, bpe_merge, tile_scan, pack, doc_offsets per
 chunk), ending with every document's token ids and offsets in HBM.
 
 N = 1 (default): BASELINE.json configs[2] -- cl100k_base, 1M mixed UTF-8 docs (emoji + CJK, ~4 KB each, ~4.1 GB), the largest
@@ -159,8 +159,8 @@ def cpu_baseline(encoding, text, doc_off, max_threads=16, ordinary=False, budget
 
 
 # ---- timing helpers ---------------------------------------------------------------------------------------------------
-STAGE_KERNEL = {"strip_encode": "k_strip_encode", "bpe_merge": "k_bpe_merge", "pretok_split": "k_pretok_split<1>",
-                "strip_expand": "k_strip_expand", "doc_offsets": "k_doc_offsets", "tile_scan": "k_tile_scan"}
+STAGE_KERNEL = {"bpe_merge": "k_bpe_merge", "piece_resolve": "k_piece_resolve", "pretok_split": "k_pretok_split<1>",
+                "pack": "k_pack_tokens", "doc_offsets": "k_doc_offsets", "tile_scan": "k_tile_scan"}
 
 
 def time_encode(torch, batches, d_text, d_off, n_docs, n_bytes, steps, warmup, ordinary, world=1, dist=None, after_step=None):

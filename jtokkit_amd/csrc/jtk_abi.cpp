@@ -45,8 +45,8 @@ struct DevBuf {
 };
 
 constexpr int N_STAGES = 8;
-const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "strip_encode", "bpe_merge",
-                                           "tile_scan", "strip_expand", "doc_offsets"};
+const char* const STAGE_NAMES[N_STAGES] = {"mark_docs", "validate_utf8", "pretok_split", "piece_resolve", "bpe_merge",
+                                           "tile_scan", "pack", "doc_offsets"};
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -72,15 +72,13 @@ struct ChunkSet {
     hipEvent_t ev_scan = nullptr;    // this set's tile_scan has run (the next chunk's scan waits for it: token order)
     hipEvent_t ev_done = nullptr;    // this set's last kernel has run
     DevBuf zeroed;                   // docmask | list counters | queue counters
-    DevBuf piecemask, gapmask, stok, hrec, htok, docpre, tile_tot, tile_off, queues, mid_list, long_list, giant_list;
+    DevBuf piecemask, gapmask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list, giant_list, giant_cnt;
     JtkWork work{};
     bool used = false;               // by the current job
 };
 
 constexpr int MAX_SETS = 4;
 constexpr int64_t SMALL_JOB_BYTES = 1 << 20;
-constexpr int64_t MEMO_MIN_JOB_BYTES = 4 << 20;   // smaller jobs merge every piece: clearing the memo would cost more than it saves
-constexpr uint32_t MEMO_SLOTS = 1u << 15;         // per XCD, 32 bytes each
 constexpr int64_t TINY_JOB_BYTES = 128 << 10;     // host jobs this small are staged so that offsets and text go down in one copy
 
 struct jtk_batch {
@@ -103,7 +101,6 @@ struct jtk_batch {
     DevBuf out;
     struct View { void* p = nullptr; };
     View job, status, tok_off, tokens;   // where those parts are in `out` for the last job
-    DevBuf memo;                     // merged pieces remembered during a job (per XCD; jtk_strip_encode.h), cleared per job
     DevBuf plan;                     // chunk plan of a device-resident batch
     int64_t* host_plan = nullptr;    // pinned
     size_t host_plan_cap = 0;
@@ -307,14 +304,14 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (ChunkSet& cs : b->set) {
         if (cs.stream) (void)hipStreamSynchronize(cs.stream);
-        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.stok, &cs.hrec, &cs.htok, &cs.docpre, &cs.tile_tot, &cs.tile_off, &cs.queues,
-                          &cs.mid_list, &cs.long_list, &cs.giant_list};
+        DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.plist, &cs.htok, &cs.docpre, &cs.tile_np, &cs.tile_off, &cs.queues, &cs.q_meta,
+                          &cs.mid_list, &cs.long_list, &cs.giant_list, &cs.giant_cnt};
         for (DevBuf* d : bufs) d->release();
         if (cs.ev_scan) (void)hipEventDestroy(cs.ev_scan);
         if (cs.ev_done) (void)hipEventDestroy(cs.ev_done);
         if (cs.stream) (void)hipStreamDestroy(cs.stream);
     }
-    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->in_pieces, &b->out, &b->memo, &b->plan, &b->dec_in_ids, &b->dec_in_off,
+    DevBuf* bufs[] = {&b->in_text, &b->in_off, &b->in_pieces, &b->out, &b->plan, &b->dec_in_ids, &b->dec_in_off,
                       &b->dec_zero, &b->dec_tile, &b->dec_pre, &b->dec_out, &b->dec_byte_off, &b->trunc_kept, &b->trunc_flag};
     for (DevBuf* d : bufs) d->release();
     for (hipEvent_t ev : b->prof_ev) (void)hipEventDestroy(ev);
@@ -392,29 +389,22 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.n_tiles = (n_bytes + 1 + JTK_TILE - 1) / JTK_TILE;
     const size_t mask_bytes = (size_t)w.n_words * 8;
     const size_t nt = (size_t)w.n_tiles;
-    w.n_shards = (uint32_t)jtk_strip_encode_grid(w.n_tiles);
-    w.enc_waves = (uint32_t)jtk_strip_encode_waves();
-    const size_t n_regions = (size_t)w.n_shards * w.enc_waves;     // waves of k_strip_encode: each fills its own region of stok / hrec
-    w.wave_cap = (uint32_t)(((size_t)w.n_tiles + n_regions - 1) / n_regions * JTK_TILE);
-    const size_t qcnt_bytes = JTK_NBINS * (size_t)JTK_MAX_Q_SHARDS * 4;
-    const size_t tot_bytes = align_up(nt * 4, 16);                  // tile_tot: zeroed with the masks and counters
-    const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes + tot_bytes;
+    const size_t qcnt_bytes = (size_t)(JTK_NBINS + 1) * JTK_Q_SHARDS * JTK_QC_STRIDE * 4;
+    const size_t zero_bytes = mask_bytes + 32 + qcnt_bytes;
     const size_t n_long_max = (size_t)n_bytes / (JTK_BIN_MAXLEN + 1) + 2;
     const size_t n_giant_max = (size_t)n_bytes / JTK_LONG_CAP + 2;
-    const size_t tps = (nt + w.n_shards - 1) / w.n_shards;          // strips per queue shard (= workgroup of k_strip_encode)
-    const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4, JTK_BIN_CAP5, JTK_BIN_CAP6};
-    size_t q_bytes = 0;
-    for (int k = 0; k < JTK_NBINS; k++) q_bytes += tps * caps[k] * w.n_shards * (k < JTK_NBINS_SHORT ? 32 : 16);
+    const size_t tps = (nt + JTK_Q_SHARDS - 1) / JTK_Q_SHARDS;      // tiles per queue shard
     int rc;
     if ((rc = cs.zeroed.ensure(zero_bytes)) || (rc = cs.piecemask.ensure(mask_bytes)) ||
-        (rc = cs.stok.ensure(n_regions * w.wave_cap * 4 + 64)) || (rc = cs.hrec.ensure(n_regions * w.wave_cap * 8 + 64)) ||
-        (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
-        (rc = cs.docpre.ensure(nt * JTK_TILE * 4 + 64)) ||
-        (rc = cs.tile_tot.ensure(align_up(nt * 4, 16) * 2 + 16)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
-        (rc = cs.queues.ensure(q_bytes)) ||
+        (rc = cs.plist.ensure(nt * JTK_TILE * 4)) || (rc = cs.htok.ensure(nt * JTK_TILE * 4 + 64)) ||
+        (rc = cs.docpre.ensure(nt * JTK_TILE * 4)) ||
+        (rc = cs.tile_np.ensure(align_up(nt * 4, 16) * 2)) || (rc = cs.tile_off.ensure((nt + 1) * 8)) ||
+        (rc = cs.q_meta.ensure(nt * 4 * 16)) ||
+        (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * ((size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4 + JTK_BIN_CAP5 + JTK_BIN_CAP6) * 24 + (size_t)JTK_TINY_CAP * 8))) ||
         (rc = cs.mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
-        (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))))
+        (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
+        (rc = cs.giant_cnt.ensure(n_giant_max * 4)))
         return rc;
     uint8_t* z = (uint8_t*)cs.zeroed.p;
     w.docmask = (uint64_t*)z;
@@ -423,22 +413,29 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
     w.n_giant = (uint32_t*)(z + mask_bytes + 8);
     w.q_count = (uint32_t*)(z + mask_bytes + 32);
     w.piecemask = (uint64_t*)cs.piecemask.p;
-    w.stok = (uint32_t*)cs.stok.p;
+    w.plist = (uint32_t*)cs.plist.p;
     w.htok = (uint32_t*)cs.htok.p;
     w.docpre = (uint32_t*)cs.docpre.p;
-    w.tile_tot = (uint32_t*)(z + mask_bytes + 32 + qcnt_bytes);
-    w.tile_np = (uint32_t*)cs.tile_tot.p;
-    w.sbase = (uint32_t*)((uint8_t*)cs.tile_tot.p + align_up(nt * 4, 16));
-    w.hrec = (uint64_t*)cs.hrec.p;
+    w.tile_np = (uint32_t*)cs.tile_np.p;
+    w.tile_tot = (uint32_t*)((uint8_t*)cs.tile_np.p + align_up(nt * 4, 16));
     w.tile_off = (int64_t*)cs.tile_off.p;
     {
-        uint8_t* qp = (uint8_t*)cs.queues.p;
+        const size_t caps[JTK_NBINS] = {JTK_BIN_CAP0, JTK_BIN_CAP1, JTK_BIN_CAP2, JTK_BIN_CAP3, JTK_BIN_CAP4, JTK_BIN_CAP5, JTK_BIN_CAP6};
+        uint8_t* qp = (uint8_t*)cs.queues.p;                      // all the 16-byte arrays first, then the 8-byte ones
+        w.q_meta = (uint32_t*)cs.q_meta.p;
         for (int k = 0; k < JTK_NBINS; k++) {
-            w.qe[k] = (uint4*)qp;
+            w.qd[k] = (uint4*)qp;
             w.q_cap[k] = (int64_t)(tps * caps[k]);
-            qp += tps * caps[k] * w.n_shards * (k < JTK_NBINS_SHORT ? 32 : 16);
+            qp += tps * caps[k] * JTK_Q_SHARDS * 16;
         }
+        for (int k = 0; k < JTK_NBINS; k++) {
+            w.qm[k] = (uint64_t*)qp;
+            qp += tps * caps[k] * JTK_Q_SHARDS * 8;
+        }
+        w.qt = (uint64_t*)qp;
+        w.qt_cap = (int64_t)(tps * JTK_TINY_CAP);
     }
+    w.giant_cnt = (uint32_t*)cs.giant_cnt.p;
     w.mid_list = (JtkLongPiece*)cs.mid_list.p;
     w.long_list = (JtkLongPiece*)cs.long_list.p;
     w.giant_list = (JtkLongPiece*)cs.giant_list.p;
@@ -493,15 +490,6 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         const size_t need = (size_t)n_chunks * N_STAGES * 2;
         while (b->prof_ev.size() < need) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); b->prof_ev.push_back(ev); }
     }
-    // the memo of merged pieces: worth its clearing for jobs of some size
-    uint4* d_memo = nullptr;
-    if (n_bytes >= MEMO_MIN_JOB_BYTES && !getenv("JTK_NO_MEMO")) {
-        const size_t memo_bytes = (size_t)8 * MEMO_SLOTS * 32;
-        if ((rc = b->memo.ensure(memo_bytes))) return rc;
-        HIP_TRY(hipMemsetAsync(b->memo.p, 0, memo_bytes, s));
-        d_memo = (uint4*)b->memo.p;
-    }
-
     const bool fork = n_chunks > 1 || (h_text != nullptr && !(n_chunks == 1 && n_bytes <= SMALL_JOB_BYTES));
     if (fork) {
         if (!b->ev_fork) {
@@ -519,6 +507,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         HIP_TRY(hipEventRecord(b->ev_fork, s));
     }
     for (ChunkSet& cs : b->set) cs.used = false;
+
     if ((rc = ensure_pinned((void**)&b->h_info, &b->h_info_cap, ((size_t)n_chunks + 1) * 16, 0))) return rc;
     // tokens of chunk c to the host: on the copy stream, after the chunk's last kernel; the host needs the chunk's token
     // range for that (written to pinned memory by its scan), so this is called one chunk behind the enqueueing
@@ -563,8 +552,6 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
         w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
         w.inline_scan = (!fork && n_chunks == 1 && w.n_tiles >= 1 && w.n_tiles <= 1024) ? 1u : 0u;
-        w.memo = d_memo;
-        w.memo_mask = MEMO_SLOTS - 1;
 
         if (fork && !cs.used) { HIP_TRY(hipStreamWaitEvent(cst, b->ev_fork, 0)); cs.used = true; }
         if (h_text && b1 > b0) {
@@ -598,10 +585,10 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
             jtk_launch_pretok_split(w, enc->dt, cst);
         }
         end();
-        begin();                                                    // every strip: dense tokens, hole bitmap, hole records; merges queued
-        jtk_launch_strip_encode(w, enc->dt, cst);
+        begin();
+        jtk_launch_piece_resolve(w, enc->dt, cst);
         end();
-        begin();                                                    // the queued pieces' hole records
+        begin();
         jtk_launch_long_shortcut(w, enc->dt, cst);                  // (only for rank tables with entries merging cannot reproduce)
         jtk_launch_bpe_merge(w, enc->dt, cst);
         end();
@@ -611,7 +598,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         if (fork) HIP_TRY(hipEventRecord(cs.ev_scan, cst));
         end();
         begin();
-        jtk_launch_strip_expand(w, cst);
+        jtk_launch_pack(w, cst);
         end();
         begin();
         jtk_launch_doc_offsets(w, cst);

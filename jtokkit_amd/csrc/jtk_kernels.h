@@ -9,35 +9,56 @@
 
 #define JTK_SPLIT_TILE 4096      // bytes per pretok_split workgroup
 #define JTK_SPLIT_HALO 64
-// A STRIP is the unit of the encode kernel: 4096 bytes = 64 piece-mask words, one per lane of the wave that encodes it.
-// Token counts, the scan and the per-document offsets are kept per strip ("tile" in the names below).
-#define JTK_TILE 4096
-// Pieces that need bytePairMerge are queued by k_strip_encode for k_bpe_merge, by length bin, in dense queues, one per bin and
-// SHARD = workgroup of k_strip_encode (which claims its entries with an atomic in LDS: no global atomic on this path -- a
-// few counters shared by the whole grid took 1 ns per claim, 5 ms per GiB of mixed text).  An entry is 16 bytes:
-//   x, y  pos (37 bits) | (len - 1) << 37   (JTK_QE_DONE: found by k_long_shortcut, nothing left to merge)
-//   z, w  index of the piece's slot and hole record (stok / hrec)
-// Bins 0..2 are pieces of up to JTK_SHORT_MAX bytes that are no table entry (the whole-piece lookup was made by
-// k_strip_encode), bins 3..6 longer ones (for which the rank table's entries of more than 16 bytes are found by merging).
-#define JTK_SHORT_MAX 16
+#define JTK_TILE 2048            // bytes per piece_resolve / pack workgroup; token counts are kept per tile
+// Pieces that need bytePairMerge are queued by length bin; bin k holds pieces of up to JTK_BIN_SLOTS(k) bytes.
+// Queues are dense and sharded: tile t appends its entries to shard t % JTK_Q_SHARDS with one returning
+// atomic per tile and bin.  A queue entry is two words in two parallel arrays:
+//   qm  (8 bytes)   pos (37 bits) | (len - 1) << 37
+//   qd  (16 bytes)  bins 0..2: IN the piece's bytes (<= 16, what piece_resolve hashed), OUT the merge result;
+//                   bins 3..6: OUT the merge result (their bytes are read from the text)
+// Merge result: (token count - 1) in the top byte | up to seven token ids, 17 bits each from bit 0; a piece that
+// became more than seven tokens leaves its tokens in htok (packed from its first byte position).  The merge kernels
+// add every piece's token count to tile_tot[tile] (piece_resolve stored the resolved pieces' count there).
 #define JTK_QE_POS_MASK ((1ull << 37) - 1ull)
 #define JTK_QE_LEN_SHIFT 37
-#define JTK_QE_DONE (1ull << 63)
-#define JTK_NBINS 7                    // queue bins: pieces of 4..8, 9..12, 13..16, 17..32, ..64, ..128, ..256 bytes
-#define JTK_NBINS_SHORT 3
-#define JTK_MAX_Q_SHARDS 1024
-#define JTK_BIN_CAP0 (JTK_TILE / 4)    // per strip: pieces of 4..8 bytes (2..3-byte pieces never need the pair table)
-#define JTK_BIN_CAP1 (JTK_TILE / 8)    //            9..12 bytes
-#define JTK_BIN_CAP2 320               //            13..16 bytes (4096 / 13 = 315)
-#define JTK_BIN_CAP3 (JTK_TILE / 16)   //            17..32 bytes
-#define JTK_BIN_CAP4 (JTK_TILE / 32)   //            33..64 bytes
-#define JTK_BIN_CAP5 (JTK_TILE / 64)   //            65..128 bytes
-#define JTK_BIN_CAP6 (JTK_TILE / 128)  //            129..256 bytes
-#define JTK_BIN_MAXLEN 256            // longer pieces go to the wave-per-piece phases
+#define JTK_QE_DONE (1ull << 63)       // the piece is a table entry found by k_long_shortcut: its result is in place already
+#define JTK_NBINS 7
+// Pieces of 2 or 3 bytes that are not table entries need no pair-table lookup at all (at most one merge of a 2-byte token;
+// the pair that would follow is the whole piece, which is not an entry).  They get a queue of their own ("bin" JTK_BIN_TINY
+// of a piece-list entry) with 8-byte entries that carry the bytes: pos (37 bits) | (len - 2) << 37 | b0 << 40 | b1 << 48 |
+// b2 << 56; the merge kernel replaces an entry by its result: up to three token ids, 17 bits each from bit 0 (the first 64
+// bits of a merge result word), | (count - 1) << 62.
+#define JTK_BIN_TINY 7
+#define JTK_TINY_CAP (JTK_TILE / 2)
+#define JTK_Q_SHARDS 64
+// Every queue counter has a 128-byte line of its own: the tiles' claims are returning atomics, and atomics on one line
+// are served one after another (about 14 ns each): with the 512 counters packed into 16 lines the claims of a GiB of mixed
+// text -- one per tile and bin -- took 1.8 ms, most of piece_resolve's time.
+#define JTK_QC_STRIDE 32
+#define JTK_QC(bin, shard) (((bin) * JTK_Q_SHARDS + (shard)) * JTK_QC_STRIDE)
+// Bins by length.  A wave of the merge kernel steps until its longest piece is done, so pieces of like length are queued
+// together: three classes up to 16 bytes (whose entries carry the piece's bytes), then powers of two.
+#define JTK_BIN_CAP0 (JTK_TILE / 4)    // per tile: pieces of 4..8 bytes (2..3-byte pieces: JTK_BIN_TINY)
+#define JTK_BIN_CAP1 (JTK_TILE / 8)    //           9..12 bytes
+#define JTK_BIN_CAP2 160               //           13..16 bytes (2048 / 13 = 157)
+#define JTK_BIN_CAP3 (JTK_TILE / 16)   //           17..32 bytes
+#define JTK_BIN_CAP4 (JTK_TILE / 32)   //           33..64 bytes
+#define JTK_BIN_CAP5 (JTK_TILE / 64)   //           65..128 bytes
+#define JTK_BIN_CAP6 (JTK_TILE / 128)  //           129..256 bytes
+// the head of a tile's slice of each bin's queue that pack stages in LDS: 32 + 16 + 16 results of the three classes of <= 16
+// bytes (staging slots 0..63), 8 of each longer bin (64..95); tiny pieces have a staging area of their own (JTK_PACK_TINY).
+// (Three times as much -- enough for every tile of CJK text -- made pack 3 % faster on mixed text and 10 % slower on prose.)
+#define JTK_PACK_TINY 128
+#define JTK_PACK_SLOTS 96
+#define JTK_PACK_CAP(bin) ((bin) == 0 ? 32 : (bin) <= 2 ? 16 : 8)
+#define JTK_PACK_OFF(bin) ((bin) == 0 ? 0 : (bin) == 1 ? 32 : (bin) == 2 ? 48 : 64 + ((bin) - 3) * 8)
+#define JTK_NBINS_BYTES 3              // bins 0..2: the queue entry carries the piece's bytes
+#define JTK_NBINS_LEAN 5               // bins 0..4: lean phases of the merge kernel; 5..6: state-machine phases
+#define JTK_BIN_MAXLEN 256            // longer pieces go to the wave-per-piece kernels
 #define JTK_M_WGS_PER_SHARD 4
-#define JTK_MID_CAP 512          // wave-per-piece phase, small bin: pieces of 257..512 bytes
-#define JTK_LONG_CAP 8192        // wave-per-piece phase, large bin
-#define JTK_GIANT_CAP (1 << 20)  // workgroup-per-piece phase with parts in global scratch (= JTK_MAX_PIECE_BYTES)
+#define JTK_MID_CAP 512          // wave-per-piece kernel, small bin: pieces of 65..512 bytes
+#define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin
+#define JTK_GIANT_CAP (1 << 20)  // workgroup-per-piece kernel with parts in global scratch (= JTK_MAX_PIECE_BYTES)
 #define JTK_GIANT_CHUNK 256      // positions per cached chunk minimum
 #define JTK_MAX_SPECIALS 8
 #define JTK_SPECIAL_MAXLEN 32
@@ -63,11 +84,24 @@ struct JtkDeviceTables {
     uint8_t special[JTK_MAX_SPECIALS][JTK_SPECIAL_MAXLEN];
 };
 
+// piece-list entry.  Resolved piece: token id (bits 0..16) | byte offset in the tile << 17.
+// Merged piece: JTK_PL_HARD | byte offset in the tile (bits 0..10) and either its queue entry (bin << 21 | index in
+// the tile's slice of the bin's queue << 11) or JTK_PL_NOQUEUE (wave / workgroup kernels: tokens and count in htok).
+#define JTK_PL_HARD 0x80000000u
+#define JTK_PL_NOQUEUE 0x40000000u
+#define JTK_PL_STAGED 0x20000000u        // queued piece whose result is in the head of the tile's queue slice that pack stages in LDS:
+                                         // the index field then holds its staging slot (pack_stage_slot), not the index in the bin
+#define JTK_PL_OFF_SHIFT 17
+#define JTK_PL_QI_SHIFT 11
+#define JTK_PL_BIN_SHIFT 21
 #define JTK_HT_ID_MASK 0x1FFFFu
+#define JTK_HT_CNT_SHIFT 17
+#define JTK_HT_CNT_MASK 0x3FFFu
+#define JTK_HT_ESCAPE 0x3FFFu            // count does not fit: giant piece, count in giant_cnt
 
-struct JtkLongPiece {       // a piece of more than JTK_BIN_MAXLEN bytes
+struct JtkLongPiece {
     int64_t start;
-    uint64_t idx_len;       // index of its slot and hole record (40 bits) | length << 40   (length 0: found by k_long_shortcut)
+    int64_t len;
 };
 
 struct JtkResult {          // of a whole batch (all its chunks)
@@ -89,38 +123,38 @@ struct JtkWork {
     int64_t n_bytes;        // from the chunk's origin to the end of its last document
     int64_t n_docs;
     int64_t n_words;        // 64-bit mask words (covers position n_bytes, plus padding)
-    int64_t n_tiles;        // strips
-    uint32_t count_only;    // countTokens(): the offsets are computed but no token ids are written
-    uint32_t inline_scan;   // small single-chunk job: the expand kernel adds up the strips before its own itself (no k_tile_scan)
+    int64_t n_tiles;
+    uint32_t count_only;    // countTokens(): pack computes the offsets but writes no token ids
+    uint32_t inline_scan;   // small single-chunk job: pack adds up the tiles before its own itself and k_tile_scan is not launched
     uint32_t check_special; // encode(): flag documents that contain a special-token literal (done inside pretok_split)
     uint64_t* docmask;      // bit p: a document starts at byte p
     uint64_t* piecemask;    // bit p: a pre-token piece starts at byte p (bit n_bytes is a sentinel)
     uint64_t* gapmask;      // NULL, or (caller-supplied pieces, jtk_batch_encode_pieces) bit p: the "piece" that starts at byte p is
                             // text between two matches of the caller's pattern: it is not encoded (matcher.find() skips it)
-    uint32_t* stok;         // [n_tiles * JTK_TILE] per strip, one slot per piece in text order: the token of a DENSE piece (<= 8 bytes,
-                            // found in its primary tok8 slot), or SLOT_HOLE
-    uint64_t* hrec;         // [n_tiles * JTK_TILE] per strip, by hole number: the hole's tokens (HR_* in jtk_strip_encode.h)
-    uint32_t* tile_np;      // [n_tiles] pieces of the strip
-    uint32_t* sbase;        // [n_tiles] where the strip's slots start in its wave's region of stok / hrec (jtk_strip_common.h)
-    uint32_t wave_cap;      // indices per wave region
-    uint32_t enc_waves;     // waves per workgroup of k_strip_encode
-    uint4* memo;            // NULL, or [8 XCDs][memo_mask + 1][2]: merged pieces remembered for the rest of the job (jtk_strip_encode.h)
-    uint32_t memo_mask;
-    uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece that became more than three tokens, packed from the
-                            // piece's first byte position (k <= len words; their hole record says how many)
-    uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its strip before it (sparse)
-    uint32_t* tile_tot;     // [n_tiles] tokens of the strip (zeroed per job; k_strip_encode adds to it)
+    uint32_t* plist;        // [n_tiles * JTK_TILE] per tile, packed from the tile's first word: its pieces in text order,
+                            // JTK_PL_* entry per piece (a piece belongs to the tile it starts in)
+    uint32_t* tile_np;      // [n_tiles] pieces in each tile's list
+    uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece without a (big enough) result slot, packed from the
+                            // piece's first byte position (k <= len words); word 0 also carries the count k: id | k << 17
+                            // (JTK_HT_ESCAPE: see giant_cnt)
+    uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its tile before it (sparse)
+    uint32_t* tile_tot;     // [n_tiles] tokens of the tile's pieces: piece_resolve stores the resolved pieces (one token
+                            // each), the merge kernels add theirs
     int64_t* tile_off;      // [n_tiles + 1] exclusive scan of tile_tot
-    uint4* qe[JTK_NBINS];           // [n_shards][q_cap[k]] queue entries of bin k
+    uint64_t* qm[JTK_NBINS];        // [JTK_Q_SHARDS][q_cap[k]] queue entries of bin k: position and length
+    uint4* qd[JTK_NBINS];           // [JTK_Q_SHARDS][q_cap[k]] ... : bytes in (bin 0), merge result out
     int64_t q_cap[JTK_NBINS];       // entries per shard
-    uint32_t* q_count;              // [JTK_NBINS][n_shards] (written by each workgroup of k_strip_encode when it is done)
-    uint32_t n_shards;              // = the grid of k_strip_encode
-    JtkLongPiece* mid_list; // pieces of 257..JTK_MID_CAP bytes
+    uint64_t* qt;                   // [JTK_Q_SHARDS][qt_cap] the queue of JTK_BIN_TINY: bytes in, result out
+    int64_t qt_cap;
+    uint32_t* q_count;              // [JTK_NBINS + 1][JTK_Q_SHARDS], one counter per 128-byte line: JTK_QC(bin, shard)
+    uint32_t* q_meta;               // [n_tiles][16]: [k] where in its shard the tile's entries of bin k start, [8 + k] how many
+    JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
     JtkLongPiece* giant_list;// pieces longer than JTK_LONG_CAP
+    uint32_t* giant_cnt;    // token count per giant_list entry
     uint32_t* mid_count;
     uint32_t* long_count;
-    uint32_t* n_giant;      // pieces longer than JTK_LONG_CAP (merged by the last phase of k_bpe_merge)
+    uint32_t* n_giant;      // pieces longer than JTK_LONG_CAP (listed by piece_resolve, merged by the last phase of k_bpe_merge_all)
     int32_t* status;        // per document
     int32_t* tokens;        // output of the whole batch, packed (tile_off already includes the earlier chunks' tokens)
     int64_t* tok_off;       // output, n_docs + 1
@@ -174,13 +208,11 @@ void jtk_launch_mark_docs(const JtkWork& w, hipStream_t s);
 void jtk_launch_mark_pieces(const JtkWork& w, const int64_t* begin, const int64_t* end, int64_t n_pieces, hipStream_t s);
 void jtk_launch_validate_utf8(const JtkWork& w, hipStream_t s);
 void jtk_launch_pretok_split(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
-int jtk_strip_encode_grid(int64_t n_tiles);                                                   // workgroups of k_strip_encode = queue shards
-int jtk_strip_encode_waves(void);                                                             // waves per workgroup
-void jtk_launch_strip_encode(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);      // every strip: dense tokens, hole bitmap, hole records; queues
+void jtk_launch_piece_resolve(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_long_shortcut(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);     // only if t.longtok.n
-void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);         // the queued pieces' hole records
+void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_t s);
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
-void jtk_launch_strip_expand(const JtkWork& w, hipStream_t s);                                // ... -> tokens, docpre
+void jtk_launch_pack(const JtkWork& w, hipStream_t s);
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s);
 
 #endif
