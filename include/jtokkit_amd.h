@@ -226,6 +226,7 @@ int jtk_service_encode(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_
 int jtk_service_submit(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
                        int32_t* tokens, int64_t tokens_cap, jtk_ticket** ticket);
 int jtk_service_wait(jtk_service* s, jtk_ticket* ticket, int64_t* n_tokens, int* truncated);
+int jtk_service_done(const jtk_ticket* ticket);     /* 1: the result is in (jtk_service_wait returns at once), 0: not yet -- a poll for callers that must not block */
 int jtk_service_stats(jtk_service* s, int64_t* n_batches, int64_t* n_docs);     /* device batches run, documents encoded */
 
 /* ---- multi-GPU: document shards and the offset stitch ------------------------------------------------------------

@@ -72,7 +72,7 @@ struct ChunkSet {
     hipEvent_t ev_scan = nullptr;    // this set's tile_scan has run (the next chunk's scan waits for it: token order)
     hipEvent_t ev_done = nullptr;    // this set's last kernel has run
     DevBuf zeroed;                   // docmask | list counters | queue counters
-    DevBuf piecemask, gapmask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list, giant_list, giant_cnt;
+    DevBuf piecemask, gapmask, plist, htok, docpre, tile_np, tile_off, queues, q_meta, mid_list, long_list, giant_list;
     JtkWork work{};
     bool used = false;               // by the current job
 };
@@ -305,7 +305,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     for (ChunkSet& cs : b->set) {
         if (cs.stream) (void)hipStreamSynchronize(cs.stream);
         DevBuf* bufs[] = {&cs.zeroed, &cs.piecemask, &cs.gapmask, &cs.plist, &cs.htok, &cs.docpre, &cs.tile_np, &cs.tile_off, &cs.queues, &cs.q_meta,
-                          &cs.mid_list, &cs.long_list, &cs.giant_list, &cs.giant_cnt};
+                          &cs.mid_list, &cs.long_list, &cs.giant_list};
         for (DevBuf* d : bufs) d->release();
         if (cs.ev_scan) (void)hipEventDestroy(cs.ev_scan);
         if (cs.ev_done) (void)hipEventDestroy(cs.ev_done);
@@ -403,8 +403,7 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
         (rc = cs.queues.ensure(tps * JTK_Q_SHARDS * ((size_t)(JTK_BIN_CAP0 + JTK_BIN_CAP1 + JTK_BIN_CAP2 + JTK_BIN_CAP3 + JTK_BIN_CAP4 + JTK_BIN_CAP5 + JTK_BIN_CAP6) * 24 + (size_t)JTK_TINY_CAP * 8))) ||
         (rc = cs.mid_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
         (rc = cs.long_list.ensure(n_long_max * sizeof(JtkLongPiece))) ||
-        (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))) ||
-        (rc = cs.giant_cnt.ensure(n_giant_max * 4)))
+        (rc = cs.giant_list.ensure(n_giant_max * sizeof(JtkLongPiece))))
         return rc;
     uint8_t* z = (uint8_t*)cs.zeroed.p;
     w.docmask = (uint64_t*)z;
@@ -435,7 +434,6 @@ int prepare_set(ChunkSet& cs, int64_t n_bytes, int64_t n_docs, size_t* bytes_to_
         w.qt = (uint64_t*)qp;
         w.qt_cap = (int64_t)(tps * JTK_TINY_CAP);
     }
-    w.giant_cnt = (uint32_t*)cs.giant_cnt.p;
     w.mid_list = (JtkLongPiece*)cs.mid_list.p;
     w.long_list = (JtkLongPiece*)cs.long_list.p;
     w.giant_list = (JtkLongPiece*)cs.giant_list.p;

@@ -40,11 +40,17 @@ struct Rccl {
 std::once_flag g_rccl_once;
 
 void load_rccl() {
-    const char* names[] = {getenv("JTK_RCCL_LIB"), "librccl.so", "librccl.so.1"};
+    // (JTK_RCCL_LIB names the library to use: then nothing else is tried)
+    const char* forced = getenv("JTK_RCCL_LIB");
+    const char* names[] = {forced, forced ? nullptr : "librccl.so", forced ? nullptr : "librccl.so.1"};
     // a copy that is already in the process (PyTorch-ROCm bundles one) first: one RCCL per process
     for (const char* n : names) if (n && !g_rccl.h) g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     for (const char* n : names) if (n && !g_rccl.h) g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rccl.h) { g_rccl.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "librccl.so"); return; }
+    if (!g_rccl.h) {
+        const char* e = dlerror();                                    // (one call: it clears the error it returns)
+        g_rccl.err = std::string("RCCL not found: ") + (e ? e : "librccl.so");
+        return;
+    }
     g_rccl.get_unique_id = (fn_get_unique_id)dlsym(g_rccl.h, "ncclGetUniqueId");
     g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(g_rccl.h, "ncclCommInitRank");
     g_rccl.comm_destroy = (fn_comm_destroy)dlsym(g_rccl.h, "ncclCommDestroy");

@@ -97,7 +97,7 @@ struct JtkDeviceTables {
 #define JTK_HT_ID_MASK 0x1FFFFu
 #define JTK_HT_CNT_SHIFT 17
 #define JTK_HT_CNT_MASK 0x3FFFu
-#define JTK_HT_ESCAPE 0x3FFFu            // count does not fit: giant piece, count in giant_cnt
+#define JTK_HT_ESCAPE 0x3FFFu            // count does not fit: giant piece, count in docpre[pos + 1]
 
 struct JtkLongPiece {
     int64_t start;
@@ -136,7 +136,7 @@ struct JtkWork {
     uint32_t* tile_np;      // [n_tiles] pieces in each tile's list
     uint32_t* htok;         // [n_tiles * JTK_TILE] tokens of a merged piece without a (big enough) result slot, packed from the
                             // piece's first byte position (k <= len words); word 0 also carries the count k: id | k << 17
-                            // (JTK_HT_ESCAPE: see giant_cnt)
+                            // (JTK_HT_ESCAPE: the count is in docpre[pos + 1])
     uint32_t* docpre;       // [n_tiles * JTK_TILE] at a document's first byte: tokens of its tile before it (sparse)
     uint32_t* tile_tot;     // [n_tiles] tokens of the tile's pieces: piece_resolve stores the resolved pieces (one token
                             // each), the merge kernels add theirs
@@ -151,7 +151,6 @@ struct JtkWork {
     JtkLongPiece* mid_list; // pieces of 65..JTK_MID_CAP bytes
     JtkLongPiece* long_list;// longer pieces
     JtkLongPiece* giant_list;// pieces longer than JTK_LONG_CAP
-    uint32_t* giant_cnt;    // token count per giant_list entry
     uint32_t* mid_count;
     uint32_t* long_count;
     uint32_t* n_giant;      // pieces longer than JTK_LONG_CAP (listed by piece_resolve, merged by the last phase of k_bpe_merge_all)

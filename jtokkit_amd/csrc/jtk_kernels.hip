@@ -415,9 +415,6 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
 // token (GptBytePairEncoding.java:81-83); every other piece is queued for bytePairMerge by length.
 // Writes the tile's piece list (plist): one word per piece, in text order.
 // ---------------------------------------------------------------------------------------------------
-#ifndef JTK_EXP
-#define JTK_EXP 0          // timing experiments (tools/r02_phases.sh): a kernel stops after one of its phases; results are wrong
-#endif
 constexpr int T = JTK_TILE;
 constexpr int TW = T / 64;                                          // mask words per tile
 static_assert(TW <= 64, "tile scans assume at most 64 mask words");
@@ -511,11 +508,6 @@ __global__ void __launch_bounds__(RES_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
-    if (JTK_EXP == 3) {   // (consistent, empty outputs: the kernels after this one have nothing to do)
-        if (tid == 0) { w.tile_np[tile] = 0; w.tile_tot[tile] = s_plist[np > 0 ? np - 1 : 0] == 0xFFFEu ? 1u : 0u; }
-        if (tid < 16) w.q_meta[tile * 16 + tid] = 0;
-        return;
-    }
     if (np == 0) {                                                   // (all waves) a tile inside one long piece
         if (tid == 0) { w.tile_np[tile] = 0; w.tile_tot[tile] = 0; }
         if (tid < 16) w.q_meta[tile * 16 + tid] = 0;
@@ -616,16 +608,15 @@ __global__ void __launch_bounds__(RES_THREADS) __attribute__((amdgpu_waves_per_e
                 else if (len64 <= JTK_LONG_CAP) w.long_list[atomicAdd(w.long_count, 1u)] = JtkLongPiece{B + s, len64};
                 else {
                     // giant piece (a run of one byte value, mostly): merged by a whole workgroup in the last phase of
-                    // k_bpe_merge; its token count goes to giant_cnt, the htok header only says so
-                    if (len64 <= JTK_GIANT_CAP) {
-                        const uint32_t gi = atomicAdd(w.n_giant, 1u);
-                        w.giant_list[gi] = JtkLongPiece{B + s, len64};
-                        w.giant_cnt[gi] = 0;
-                    } else {
+                    // k_bpe_merge; its token count goes to docpre[pos + 1] (a position inside the piece: no document starts
+                    // there, so pack never writes that word), the htok header only says so
+                    w.docpre[B + s + 1] = 0u;
+                    if (len64 <= JTK_GIANT_CAP) w.giant_list[atomicAdd(w.n_giant, 1u)] = JtkLongPiece{B + s, len64};
+                    else {
                         const int64_t d = find_doc(w, B + s);
                         if (d >= 0) atomicMin(&w.status[d], -10 /* JTK_ERR_PIECE_TOO_LONG */);
                     }
-                    w.htok[B + s] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;         // count: giant_cnt, or none at all
+                    w.htok[B + s] = (uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT;         // count: docpre[pos + 1]
                 }
                 atomicAdd(&s_nhard, 1u);
             }
@@ -662,11 +653,6 @@ __global__ void __launch_bounds__(RES_THREADS) __attribute__((amdgpu_waves_per_e
     // A tile with few merge pieces (ordinary text) leaves that to wave 0; the other waves are done and leave, so
     // their slots go to the next tile's workgroup while the atomic is in flight.
     const uint32_t n_queued = s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3] + s_qn[4] + s_qn[5] + s_qn[6] + s_qn[JTK_BIN_TINY];
-    if (JTK_EXP == 4) {
-        if (tid == 0) { w.tile_np[tile] = 0; w.tile_tot[tile] = n_queued == 0xFFFFFFu ? 1u : 0u; }
-        if (tid < 16) w.q_meta[tile * 16 + tid] = 0;
-        return;
-    }
     const bool all_waves = n_queued > 64u;                           // workgroup-uniform
     if (!all_waves && wv != 0) return;
     if (wv == 0) {
@@ -1484,7 +1470,7 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
         __syncthreads();
     }
     // emit (wave 0): surviving ids packed in place from the piece's first position (a survivor never moves up);
-    // count in giant_cnt
+    // count in docpre[start + 1] (the pair ranks kept there are no longer needed)
     if (wv == 0) {
         uint32_t total = 0;
         uint32_t first = 0;
@@ -1500,7 +1486,7 @@ __device__ void merge_giant(const JtkWork& w, const JtkDeviceTables& t, const Gi
         }
         if (lane == 0) {
             gid[0] = first | ((uint32_t)JTK_HT_ESCAPE << JTK_HT_CNT_SHIFT);
-            w.giant_cnt[gi] = total;
+            grk[1] = total;
             atomicAdd(&w.tile_tot[lp.start / T], total);
         }
     }
@@ -1652,10 +1638,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(JtkWork w) {
 __device__ __forceinline__ uint32_t hard_count(const JtkWork& w, int64_t pos) {
     const uint32_t c = (w.htok[pos] >> JTK_HT_CNT_SHIFT) & JTK_HT_CNT_MASK;
     if (c != JTK_HT_ESCAPE) return c;
-    const uint32_t ng = *w.n_giant;                         // giant piece: look its count up (rare)
-    for (uint32_t i = 0; i < ng; i++)
-        if (w.giant_list[i].start == pos) return w.giant_cnt[i];
-    return 0;                                               // longer than JTK_GIANT_CAP: no tokens, status set
+    return w.docpre[pos + 1];                               // giant piece (longer than JTK_GIANT_CAP: 0 tokens, status set)
 }
 
 // c token ids from htok to the output, eight loads in flight per round trip (htok is padded by 16 words)
@@ -1762,7 +1745,6 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
 #pragma unroll
     for (int j = 0; j < 8; j++) e[j] = (j * 64 + lane < np) ? e[j] : 0u;
     wave_lds_fence();
-    if (JTK_EXP == 1) { uint32_t x = 0; for (int j = 0; j < 8; j++) x ^= e[j]; if (x == 0x12345u) dst[lane] = s_qe[lane].x + (uint32_t)s_qt[lane].x; return; }
     uint32_t run = 0;
     // a tiny piece's 8-byte result as a merge result word: the ids are where res_tok<0..2> looks, the count moves up
     auto tiny_word = [](uint2 r) { return make_uint4(r.x, r.y & 0x3FFFFFFFu, 0u, (r.y >> 30) << 24); };
@@ -1849,7 +1831,6 @@ __global__ void __launch_bounds__(64) k_pack_tokens(JtkWork w) {
             else step(dst, e[j], k0 + j * 64 + lane);
         }
     }
-    if (JTK_EXP == 2) { if (s_out[lane] == 0x12345u) dst[lane] = run; return; }
     if (stage && store) {
         wave_lds_fence();
         for (uint32_t i = lane; i < total; i += WAVE) dst[i] = s_out[i];

@@ -40,14 +40,15 @@ struct jtk_ticket {
     int64_t n_tokens = 0;
     int truncated = 0;
     int status = JTK_OK;
-    std::atomic<int> done{0};        // set by the worker (release); the waiter spins briefly, then sleeps on it (futex)
-    std::atomic<int> sleeping{0};
+    // ONE word says where the ticket is: 0 pending, 1 done, 2 pending with its waiter asleep on this word (futex).  The worker
+    // publishes with an exchange and never touches the ticket again: the waiter may delete it the moment it reads 1.
+    std::atomic<int> state{0};
 };
 
 struct jtk_service {
     const jtk_encoding* enc = nullptr;
     int device = 0;
-    int64_t max_docs = 1 << 16, max_bytes = (int64_t)64 << 20;
+    int64_t max_docs = 1 << 16, max_bytes = (int64_t)64 << 20;     // a device batch takes at most this much; the rest stays queued
     // The queue is sharded by producer thread: a producer holds its shard's lock for one push_back, so producers contend
     // with one another only when they share a shard (one mutex for all of them capped 8 producers at a fifth of what 2 reach).
     static constexpr int N_SHARDS = 16;
@@ -57,6 +58,7 @@ struct jtk_service {
     };
     Shard shards[N_SHARDS];
     std::atomic<unsigned> next_shard{0};
+    unsigned id = 0;                  // (a thread remembers its shard per service)
     std::atomic<int> pending{0};      // documents queued; idle workers sleep on it (futex)
     std::atomic<int> idle{0};
     std::atomic<bool> stop{false};
@@ -92,17 +94,30 @@ void worker_main(jtk_service* s) {
             s->idle.fetch_sub(1);
         }
         {
-            // (a document pushed after its shard was emptied stays for the next round: `pending` is reduced by what was taken)
+            // (a document pushed after its shard was visited stays for the next round: `pending` is reduced by what was taken;
+            // so does what exceeds max_docs / max_bytes: a device batch and its pinned staging are bounded)
             int taken = 0;
+            int64_t bytes = 0;
             for (auto& sh : s->shards) {
                 std::lock_guard<std::mutex> lk(sh.mu);
-                taken += (int)sh.queue.size();
-                take.insert(take.end(), sh.queue.begin(), sh.queue.end());
-                sh.queue.clear();
+                size_t k = 0;
+                while (k < sh.queue.size() && (int64_t)take.size() < s->max_docs && (take.empty() || bytes + sh.queue[k]->len <= s->max_bytes)) {
+                    bytes += sh.queue[k]->len;
+                    take.push_back(sh.queue[k++]);
+                }
+                taken += (int)k;
+                sh.queue.erase(sh.queue.begin(), sh.queue.begin() + (long)k);
             }
             s->pending.fetch_sub(taken, std::memory_order_acq_rel);
         }
-        if (take.empty()) { if (s->stop.load()) break; continue; }
+        if (take.empty()) {
+            if (s->stop.load()) {
+                bool left = false;                                    // (leave only when nothing is queued: tickets are never stranded)
+                for (auto& sh : s->shards) { std::lock_guard<std::mutex> lk(sh.mu); left = left || !sh.queue.empty(); }
+                if (!left) break;
+            }
+            continue;
+        }
         // encode() and encodeOrdinary() callers (and count-only ones) form separate device batches
         for (int pass = 0; pass < 4 && !take.empty(); pass++) {
             const uint32_t want = (pass & 1 ? JTK_ENCODE_ORDINARY : 0u) | (pass & 2 ? JTK_ENCODE_COUNT_ONLY : 0u);
@@ -158,8 +173,8 @@ void worker_main(jtk_service* s) {
             s->n_docs += (int64_t)group.size();
         }
         for (jtk_ticket* t : take) {
-            t->done.store(1, std::memory_order_seq_cst);
-            if (t->sleeping.load(std::memory_order_seq_cst)) futex_wake(&t->done, 1);
+            std::atomic<int>* st = &t->state;
+            if (st->exchange(1, std::memory_order_seq_cst) == 2) futex_wake(st, 1);    // (only the address is used after the exchange)
         }
     }
     if (h_text) jtk_host_free(h_text);
@@ -178,6 +193,8 @@ int jtk_service_create(const jtk_encoding* enc, int n_workers, jtk_service** out
     if (n_workers > 16) n_workers = 16;
     jtk_service* s = new (std::nothrow) jtk_service();
     if (!s) return jtk_fail_msg(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
+    static std::atomic<unsigned> next_id{1};
+    s->id = next_id.fetch_add(1);
     s->enc = enc;
     s->device = jtk_encoding_device(enc);
     for (int i = 0; i < n_workers; i++) s->workers.emplace_back(worker_main, s);
@@ -187,8 +204,13 @@ int jtk_service_create(const jtk_encoding* enc, int n_workers, jtk_service** out
 
 void jtk_service_destroy(jtk_service* s) {
     if (!s) return;
-    s->stop.store(true);
-    s->pending.fetch_add(1);                                     // wakes idle workers; they find an empty queue and leave
+    {
+        // no submit slips in behind the workers: `stop` is set with every shard locked, and submit checks it under its shard's lock
+        for (auto& sh : s->shards) sh.mu.lock();
+        s->stop.store(true);
+        for (auto& sh : s->shards) sh.mu.unlock();
+    }
+    s->pending.fetch_add(1);                                     // wakes idle workers; they drain the queues and leave
     futex_wake(&s->pending, INT_MAX);
     for (auto& t : s->workers) t.join();
     delete s;
@@ -201,12 +223,13 @@ int jtk_service_submit(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_
     if (!t) return jtk_fail_msg(JTK_ERR_OUT_OF_MEMORY, "out of host memory");
     t->utf8 = utf8; t->len = len; t->flags = flags & (JTK_ENCODE_ORDINARY | JTK_ENCODE_COUNT_ONLY); t->max_tokens = max_tokens;
     t->tokens = tokens; t->cap = tokens_cap;
-    if (s->stop.load()) { delete t; return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "service is shutting down"); }
     {
-        static thread_local unsigned my_shard = ~0u;
-        if (my_shard == ~0u) my_shard = s->next_shard.fetch_add(1) % (unsigned)jtk_service::N_SHARDS;
+        // a thread keeps one shard per service (the last service it used is remembered)
+        static thread_local unsigned my_service = 0, my_shard = 0;
+        if (my_service != s->id) { my_service = s->id; my_shard = s->next_shard.fetch_add(1) % (unsigned)jtk_service::N_SHARDS; }
         jtk_service::Shard& sh = s->shards[my_shard];
         std::lock_guard<std::mutex> lk(sh.mu);
+        if (s->stop.load()) { delete t; return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "service is shutting down"); }
         sh.queue.push_back(t);
         s->pending.fetch_add(1, std::memory_order_release);
     }
@@ -217,10 +240,11 @@ int jtk_service_submit(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_
 
 int jtk_service_wait(jtk_service* s, jtk_ticket* t, int64_t* n_tokens, int* truncated) {
     if (!s || !t) return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
-    for (int spin = 0; spin < 2000 && !t->done.load(std::memory_order_acquire); spin++) __builtin_ia32_pause();
-    if (!t->done.load(std::memory_order_acquire)) {
-        t->sleeping.store(1, std::memory_order_seq_cst);
-        while (!t->done.load(std::memory_order_seq_cst)) futex_wait(&t->done, 0);
+    for (int spin = 0; spin < 2000 && t->state.load(std::memory_order_acquire) != 1; spin++) __builtin_ia32_pause();
+    if (t->state.load(std::memory_order_acquire) != 1) {
+        int expect = 0;
+        t->state.compare_exchange_strong(expect, 2, std::memory_order_seq_cst);      // 0 -> 2: asleep (or it just became 1)
+        while (t->state.load(std::memory_order_seq_cst) != 1) futex_wait(&t->state, 2);
     }
     const int rc = t->status;
     if (n_tokens) *n_tokens = t->n_tokens;
@@ -231,6 +255,8 @@ int jtk_service_wait(jtk_service* s, jtk_ticket* t, int64_t* n_tokens, int* trun
     if (rc != JTK_OK) return jtk_fail_msg(rc, "document could not be encoded");
     return JTK_OK;
 }
+
+int jtk_service_done(const jtk_ticket* t) { return t && t->state.load(std::memory_order_acquire) == 1 ? 1 : 0; }
 
 int jtk_service_encode(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_t flags, int64_t max_tokens,
                        int32_t* tokens, int64_t tokens_cap, int64_t* n_tokens, int* truncated) {

@@ -87,7 +87,11 @@ class HostBuffer:
             N.lib().jtk_host_free(self._p)
             self._p = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # (interpreter shutdown: the module's globals may be gone)
+            pass
 
 
 class Batch:
@@ -104,7 +108,11 @@ class Batch:
             N.lib().jtk_batch_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # (interpreter shutdown: the module's globals may be gone)
+            pass
 
     def set_option(self, option, value):
         """jtk_batch_set_option: N.JTK_OPT_CHUNK_BYTES, N.JTK_OPT_CHUNKS_IN_FLIGHT."""
@@ -241,7 +249,7 @@ class Batch:
         nt = C.c_int64(0)
         tr = C.c_int(0)
         _check(N.lib().jtk_encode(self._h, bytes(b), len(b), N.JTK_ENCODE_ORDINARY if ordinary else 0,
-                                  -1 if max_tokens is None else int(max_tokens), out.ctypes.data, cap,
+                                  -1 if max_tokens is None else max(0, int(max_tokens)), out.ctypes.data, cap,
                                   C.byref(nt), C.byref(tr)))
         return out[:nt.value].tolist(), bool(tr.value)
 
@@ -312,7 +320,7 @@ class HipEncoding:
         nt = C.c_int64(0)
         tr = C.c_int(0)
         _check(N.lib().jtk_service_encode(self._service(), bytes(b), len(b), N.JTK_ENCODE_ORDINARY if ordinary else 0,
-                                          -1 if max_tokens is None else int(max_tokens), out.ctypes.data, cap,
+                                          -1 if max_tokens is None else max(0, int(max_tokens)), out.ctypes.data, cap,
                                           C.byref(nt), C.byref(tr)))
         return out[:nt.value].tolist(), bool(tr.value)
 

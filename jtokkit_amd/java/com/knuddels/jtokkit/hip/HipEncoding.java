@@ -116,7 +116,9 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 
 	@Override
 	public EncodingResult encode(final String text, final int maxTokens) {
-		return encodeInternal(text, 0, maxTokens);
+		// (a negative maxTokens: the reference's loop never runs -- GptBytePairEncoding.java:79 -- which is what 0 gives: an
+		// empty list, truncated iff the text is not empty; -1 is the C ABI's "no limit")
+		return encodeInternal(text, 0, Math.max(maxTokens, 0));
 	}
 
 	@Override
@@ -126,7 +128,89 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 
 	@Override
 	public EncodingResult encodeOrdinary(final String text, final int maxTokens) {
-		return encodeInternal(text, 1, maxTokens);
+		return encodeInternal(text, 1, Math.max(maxTokens, 0));
+	}
+
+	// ---- the same without blocking: many documents in flight per thread -----------------------------
+
+	/**
+	 * {@link #encode(String)} as a future: the document is handed to the service (jtk_service_submit) and the calling
+	 * thread goes on; a daemon thread of this object waits for the tickets in submission order (jtk_service_wait) and
+	 * completes the futures.  This is the fast route for the reference's per-call shape
+	 * (benchmark/.../AbstractMultiThreadedBenchmark.java:35-45: one task per document): a few threads keep thousands of
+	 * documents in flight, so the device batches are large.
+	 */
+	public java.util.concurrent.CompletableFuture<List<Integer>> encodeAsync(final String text) {
+		return submit(text, 0);
+	}
+
+	public java.util.concurrent.CompletableFuture<List<Integer>> encodeOrdinaryAsync(final String text) {
+		return submit(text, 1);
+	}
+
+	private java.util.concurrent.CompletableFuture<List<Integer>> submit(final String text, final int flags) {
+		final java.util.concurrent.CompletableFuture<List<Integer>> f = new java.util.concurrent.CompletableFuture<>();
+		if (text == null) {
+			f.complete(Collections.emptyList());
+			return f;
+		}
+		if (hostPattern != null) {
+			f.complete(encodeInternal(text, flags, -1).getTokens());
+			return f;
+		}
+		final long ticket = nativeServiceSubmit(serviceHandle, text.getBytes(StandardCharsets.UTF_8), flags);
+		synchronized (inFlight) {
+			inFlight.add(new Pending(ticket, f));
+			if (completer == null) {
+				completer = new Thread(this::completeLoop, "jtokkit-amd-completer");
+				completer.setDaemon(true);
+				completer.start();
+			}
+			inFlight.notifyAll();
+		}
+		return f;
+	}
+
+	private static final class Pending {
+		final long ticket;
+		final java.util.concurrent.CompletableFuture<List<Integer>> future;
+
+		Pending(final long ticket, final java.util.concurrent.CompletableFuture<List<Integer>> future) {
+			this.ticket = ticket;
+			this.future = future;
+		}
+	}
+
+	private final java.util.ArrayDeque<Pending> inFlight = new java.util.ArrayDeque<>();
+	private Thread completer;
+
+	private void completeLoop() {
+		for (;;) {
+			final Pending p;
+			synchronized (inFlight) {
+				while (inFlight.isEmpty()) {
+					if (closed) {
+						return;
+					}
+					try {
+						inFlight.wait(100);
+					} catch (final InterruptedException e) {
+						return;
+					}
+				}
+				p = inFlight.poll();
+			}
+			try {
+				final int[] ids = nativeServiceWait(serviceHandle, p.ticket);      // throws what encode() would
+				final List<Integer> out = new ArrayList<>(ids.length);
+				for (final int id : ids) {
+					out.add(id);
+				}
+				p.future.complete(out);
+			} catch (final RuntimeException e) {
+				p.future.completeExceptionally(e);
+			}
+		}
 	}
 
 	@Override
@@ -367,6 +451,15 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 			return;
 		}
 		closed = true;
+		synchronized (inFlight) {                                          // (the service's workers finish what is queued before they leave)
+			while (!inFlight.isEmpty()) {
+				try {
+					inFlight.wait(10);
+				} catch (final InterruptedException e) {
+					break;
+				}
+			}
+		}
 		nativeServiceDestroy(serviceHandle);
 		for (final long b : allBatches) {
 			nativeBatchDestroy(b);
@@ -382,6 +475,8 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 	private static native long nativeServiceCreate(long encoding, int workers);
 	private static native void nativeServiceDestroy(long service);
 	private static native int[] nativeServiceEncode(long service, byte[] utf8, int flags, int maxTokens, boolean[] truncated);
+	private static native long nativeServiceSubmit(long service, byte[] utf8, int flags);
+	private static native int[] nativeServiceWait(long service, long ticket);
 	private static native long nativeBatchCreate(long encoding);
 	private static native void nativeBatchDestroy(long batch);
 	private static native BatchResult nativeEncodeBatch(long batch, ByteBuffer utf8, long[] docOff, int flags);

@@ -82,7 +82,8 @@ JNIEXPORT jintArray JNICALL FN(nativeServiceEncode)(JNIEnv* env, jclass c, jlong
     jbyte* bytes = (*env)->GetByteArrayElements(env, utf8, NULL);
     int32_t* toks = (int32_t*)malloc(((size_t)len + 1) * sizeof(int32_t));     /* tokens <= bytes */
     int64_t n = 0; int tr = 0;
-    int rc = jtk_service_encode(SVC(svc), (const uint8_t*)bytes, len, (uint32_t)flags, maxTokens, toks, (int64_t)len + 1, &n, &tr);
+    /* (only JTK_ENCODE_ORDINARY passes: a count-only call would leave `toks` unwritten) */
+    int rc = jtk_service_encode(SVC(svc), (const uint8_t*)bytes, len, (uint32_t)flags & JTK_ENCODE_ORDINARY, maxTokens, toks, (int64_t)len + 1, &n, &tr);
     (*env)->ReleaseByteArrayElements(env, utf8, bytes, JNI_ABORT);
     if (rc != JTK_OK) { free(toks); throw_for(env, rc); return NULL; }
     jintArray out = (*env)->NewIntArray(env, (jsize)n);
@@ -90,6 +91,36 @@ JNIEXPORT jintArray JNICALL FN(nativeServiceEncode)(JNIEnv* env, jclass c, jlong
     free(toks);
     jboolean jt = tr ? JNI_TRUE : JNI_FALSE;
     (*env)->SetBooleanArrayRegion(env, truncated, 0, 1, &jt);
+    return out;
+}
+
+/* encodeAsync: the two halves of the above.  The document's bytes and the token buffer live in one native block until the
+ * ticket has been waited for (the service reads and writes them from its worker threads). */
+typedef struct { jtk_ticket* ticket; int64_t len; int32_t* toks; uint8_t bytes[]; } jtk_jni_pending;
+
+JNIEXPORT jlong JNICALL FN(nativeServiceSubmit)(JNIEnv* env, jclass c, jlong svc, jbyteArray utf8, jint flags) {
+    (void)c;
+    jsize len = (*env)->GetArrayLength(env, utf8);
+    const size_t text_bytes = ((size_t)len + 7) & ~(size_t)7;
+    jtk_jni_pending* p = (jtk_jni_pending*)malloc(sizeof(jtk_jni_pending) + text_bytes + ((size_t)len + 1) * sizeof(int32_t));
+    if (!p) { throw_for(env, JTK_ERR_OUT_OF_MEMORY); return 0; }
+    (*env)->GetByteArrayRegion(env, utf8, 0, len, (jbyte*)p->bytes);
+    p->len = len;
+    p->toks = (int32_t*)(p->bytes + text_bytes);
+    int rc = jtk_service_submit(SVC(svc), p->bytes, len, (uint32_t)flags & JTK_ENCODE_ORDINARY, -1, p->toks, (int64_t)len + 1, &p->ticket);
+    if (rc != JTK_OK) { free(p); throw_for(env, rc); return 0; }
+    return (jlong)(intptr_t)p;
+}
+
+JNIEXPORT jintArray JNICALL FN(nativeServiceWait)(JNIEnv* env, jclass c, jlong svc, jlong pending) {
+    (void)c;
+    jtk_jni_pending* p = (jtk_jni_pending*)(intptr_t)pending;
+    int64_t n = 0;
+    int rc = jtk_service_wait(SVC(svc), p->ticket, &n, NULL);
+    if (rc != JTK_OK) { free(p); throw_for(env, rc); return NULL; }
+    jintArray out = (*env)->NewIntArray(env, (jsize)n);
+    (*env)->SetIntArrayRegion(env, out, 0, (jsize)n, (const jint*)p->toks);
+    free(p);
     return out;
 }
 

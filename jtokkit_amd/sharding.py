@@ -68,7 +68,11 @@ class Comm:
             N.lib().jtk_comm_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # (interpreter shutdown: the module's globals may be gone)
+            pass
 
 
 def shard_by_bytes(doc_off, world_size):

@@ -293,3 +293,56 @@ def test_cpp_mirror_encodes_on_the_device(tmp_path):
     exe = _build_mirror_smoke(tmp_path)
     p = subprocess.run([exe, os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken")], capture_output=True, text=True)
     assert p.returncode == 0 and "mirror ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+# ---- the Java shim and its JNI glue are source only (no JDK here): at least their seams must agree ------------------------
+def _java_natives():
+    import re
+    src = open(os.path.join(ROOT, "jtokkit_amd", "java", "com", "knuddels", "jtokkit", "hip", "HipEncoding.java")).read()
+    out = {}
+    for m in re.finditer(r"private static native\s+([\w\[\].]+)\s+(\w+)\s*\(([^)]*)\)\s*;", src, re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        types = [a.split()[-2] if len(a.split()) >= 2 else a for a in (x.strip() for x in args.split(",")) if a]
+        out[name] = (ret, types)
+    return out
+
+
+def _jni_functions():
+    import re
+    src = open(os.path.join(ROOT, "jtokkit_amd", "java", "jtk_jni.c")).read()
+    out = {}
+    for m in re.finditer(r"JNIEXPORT\s+(\w+)\s+JNICALL\s+FN\((\w+)\)\s*\(([^)]*)\)", src, re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        types = [a.split()[0] for a in (x.strip() for x in args.split(",")) if a]
+        assert types[:2] == ["JNIEnv*", "jclass"], (name, types)
+        out[name] = (ret, types[2:])
+    return out
+
+
+_JNI_TYPE = {"long": "jlong", "int": "jint", "void": "void", "boolean": "jboolean", "byte[]": "jbyteArray", "int[]": "jintArray",
+             "long[]": "jlongArray", "boolean[]": "jbooleanArray", "String": "jstring", "String[]": "jobjectArray",
+             "byte[][]": "jobjectArray", "ByteBuffer": "jobject", "BatchResult": "jobject"}
+
+
+def test_java_native_declarations_match_the_jni_glue():
+    """Every `native` method of HipEncoding.java has a Java_..._<name> function in jtk_jni.c with the same argument and result
+    types (and the other way round): the two files are never compiled here, so this is the only check of that seam."""
+    java, glue = _java_natives(), _jni_functions()
+    assert len(java) >= 16 and set(java) == set(glue), (sorted(set(java) ^ set(glue)))
+    for name, (ret, types) in java.items():
+        assert (_JNI_TYPE[ret], [_JNI_TYPE[t] for t in types]) == glue[name], (name, java[name], glue[name])
+
+
+def test_missing_rccl_is_a_status_code_with_a_message():
+    """jtk_comm_* bind RCCL at run time; a library that cannot be loaded must come back as JTK_ERR_HIP with a message, not as a
+    crash (dlerror() clears the message it returns: calling it twice handed NULL to std::string)."""
+    code = ("import ctypes as C\n"
+            "L = C.CDLL(%r)\n"
+            "L.jtk_last_error.restype = C.c_char_p\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "rc = L.jtk_comm_unique_id(buf)\n"
+            "print(rc, L.jtk_last_error().decode())\n") % os.path.join(ROOT, "jtokkit_amd", "libjtokkit_amd.so")
+    env = dict(os.environ, JTK_RCCL_LIB="/nonexistent/librccl.so")
+    p = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, (p.returncode, p.stderr[-300:])
+    rc, msg = p.stdout.split(" ", 1)
+    assert int(rc) == -8 and "RCCL not found" in msg and "nonexistent" in msg, p.stdout

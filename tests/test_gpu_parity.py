@@ -3,6 +3,7 @@
   (2) the CPU oracle (oracle/jtk_oracle.cpp) on seeded synthetic inputs, bit-exact token ids.
 Every test here needs a real MI355X (`-m gpu`).
 """
+import os
 import random
 
 import numpy as np
@@ -15,6 +16,7 @@ import regex_crosscheck as rc
 pytestmark = pytest.mark.gpu
 
 NAMES = golden_util.ENCODING_NAMES
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -874,3 +876,17 @@ def test_hand_made_rank_table_with_unreproducible_entries(jt, kind):
     assert enc.encode("[stop]] ~end <|x") == o.encode("[stop]] ~end <|x")
     assert enc.decode([100000, 100001]) == "[[stop]]~end~"
     enc.close()
+
+
+def test_service_tickets_polled_by_spinning(tmp_path):
+    """The completion hand-off of the per-call service (jtk_service.cpp: one state word per ticket, published with an exchange):
+    16 native threads, 200k documents, every ticket polled with jtk_service_done and collected -- and so freed -- the moment it
+    reads done; every result against the oracle (tests/cpp/service_spin.cpp)."""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "service_spin")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "service_spin.cpp"), "-ldl"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([exe, os.path.join(ROOT, "jtokkit_amd", "libjtokkit_amd.so"), os.path.join(ROOT, "oracle", "libjtk_oracle.so"),
+                        os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken"), "16", "200000", "64"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "spin ok: 200000 documents" in p.stdout, (p.returncode, p.stdout[-300:], p.stderr[-300:])
