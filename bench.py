@@ -235,6 +235,23 @@ def verify_sample(enc_name, batch, text, doc_off, n_sample, ordinary, seed=0):
     return len(sample)
 
 
+def verify_host_sample(enc_name, res, text, doc_off, n_sample, ordinary, seed=3):
+    """The same check on a result that already lives in host memory (the end-to-end path)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    o = oracle_lib.get(enc_name)
+    n_docs = len(doc_off) - 1
+    assert int(res.tok_off[-1]) == len(res.tokens) and (np.diff(res.tok_off) >= 0).all() and (res.status == 0).all()
+    rng = np.random.default_rng(seed)
+    sample = np.sort(rng.choice(n_docs, min(n_docs, n_sample), replace=False))
+    for d in sample:
+        doc = text[doc_off[d]:doc_off[d + 1]].tobytes()
+        exp = o.encode_ordinary(doc) if ordinary else o.encode(doc)
+        if res.tokens[res.tok_off[d]:res.tok_off[d + 1]].tolist() != exp:
+            raise SystemExit("bench: document %d of the end-to-end result differs from the oracle" % int(d))
+    return len(sample)
+
+
 def traffic_for(workload_key, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this workload (profiles/pmc_traffic.json), collected
     and corrected as MI355X_MICROARCH.md prescribes (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 on gfx950)."""
@@ -261,6 +278,7 @@ def main():
                     help="time encodeOrdinary() instead of encode() (skips the special-token check of GptBytePairEncoding.java:52-56)")
     ap.add_argument("--no-verify", action="store_true", help="skip the after-the-clock check of a document sample against the oracle")
     ap.add_argument("--no-subrecords", action="store_true", help="headline only")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4_full sub-record (10M documents on one GPU: about two minutes)")
     ap.add_argument("--chunk-mb", type=int, default=None, help="JTK_OPT_CHUNK_BYTES in MiB (library default: 1024)")
     ap.add_argument("--in-flight", type=int, default=None, help="JTK_OPT_CHUNKS_IN_FLIGHT (library default: 2)")
     ap.add_argument("--serial", action="store_true", help="one chunk at a time (clean per-kernel times, no overlap)")
@@ -294,6 +312,7 @@ def main():
             b.set_option(N.JTK_OPT_CHUNKS_IN_FLIGHT, 1)
         elif args.in_flight:
             b.set_option(N.JTK_OPT_CHUNKS_IN_FLIGHT, args.in_flight)
+        b.set_option(N.JTK_OPT_REUSE_CHUNK_PLAN, 1)               # the step loop hands the same offsets array every step
         b.set_profiling(True)
         return b
 
@@ -303,17 +322,17 @@ def main():
         total_docs = args.docs or 1000000
         text, doc_off = make_corpus("mixed", total_docs, 3, workers)
         wl = "%s, %s mixed UTF-8 docs (emoji + CJK, ~4 KB each)" % (args.encoding, "1M" if total_docs == 1000000 else str(total_docs))
-        wl_key, scaling = "cfg3", "weak"
+        wl_key, scaling = "cfg3", "strong"
     elif wl_name == "cfg2":
         total_docs = args.docs or 100000
         text, doc_off = make_corpus("english", total_docs, 2, workers)
         wl = "%s, %dk synthetic English docs (~1 KB each)" % (args.encoding, total_docs // 1000)
-        wl_key, scaling = "cfg2", "weak"
+        wl_key, scaling = "cfg2", "strong"
     elif wl_name == "vocab":
         total_docs = args.docs or 100000
         text, doc_off = vocab_stress_corpus(total_docs)
         wl = "%s, %dk vocabulary-stress docs (uniformly random rank-table entries)" % (args.encoding, total_docs // 1000)
-        wl_key, scaling = "vocab", "weak"
+        wl_key, scaling = "vocab", "strong"
     else:
         total_docs = args.docs or 10000000
         # contiguous document ranges of the 10M-doc corpus (corpus shards of 100k docs, seed 4 + shard index), one per rank
@@ -422,9 +441,22 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "verified": verified,
         }
+        if world > 1:
+            # what every rank did (max over ranks is the clock): bytes and seconds per rank, the communicator the stitch ran on
+            out["per_rank"] = {"MBps": [round(float(r[1]) * steps / float(r[0]) / 1e6, 1) for r in allst],
+                               "bytes": [int(r[1]) for r in allst], "tokens": [int(r[2]) for r in allst]}
+            out["rccl_world"] = comm.comm_world() if comm is not None else None
+            out["stitch"] = ("jtk_comm_stitch: ncclAllGather of the shard token totals (1 x int64 per rank) on the batch's stream, every step"
+                             if comm is not None else "rehearsal on one GPU: torch.distributed (gloo) all_gather of the totals")
+        else:
+            out["scaling_note"] = ("N = 1 times configs[2]; the N > 1 lines time configs[3] (10M English docs) sharded over N GPUs: the "
+                                   "one-GPU point of that curve is the cfg4_full sub-record of this line")
     if world == 1 and not args.no_subrecords:
         sub = {}
-        subrecords(sub, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, d_text, d_off, workers, wl_name)
+        batch.close()                                                   # (its scratch: ~74 GB for 1 GiB chunks)
+        dev_arrays = {"text": d_text, "off": d_off}
+        del d_text, d_off
+        subrecords(sub, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev_arrays, workers, wl_name)
         out.update(sub)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -479,10 +511,27 @@ def batch_chunks(batch, n_bytes, args):
     return list(range((n_bytes + cb - 1) // cb))
 
 
-def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, d_text, d_off, workers, wl_name):
+def pcie_rates(torch, dev, mb=1024):
+    """Pinned host <-> device copy rates of this box (one direction at a time), for the end-to-end record."""
+    h = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
+    d = torch.empty(mb << 20, dtype=torch.uint8, device=dev)
+    out = {}
+    for name, (dst, src) in (("h2d", (d, h)), ("d2h", (h, d))):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        out[name] = (mb << 20) * 3 / (time.perf_counter() - t0) / 1e9
+    return out
+
+
+def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev_arrays, workers, wl_name):
     """N = 1: the other BASELINE.json configs and the measurements next to the headline, each checked against the oracle
     after its clock."""
     n_docs, n_bytes = len(doc_off) - 1, int(doc_off[-1])
+    d_text, d_off = dev_arrays["text"], dev_arrays["off"]
     enc = jtokkit_amd.get_encoding("cl100k_base", device=0)
 
     def rate(nb, dt, steps):
@@ -574,19 +623,59 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, d_t
         for b in bs.values():
             b.close()
 
-    # ---- one shard of configs[3] on one GPU: the N = 1 point of the 10M-doc strong-scaling curve (1.25M English docs)
+    # ---- end to end on the headline workload: pinned host text in -> token ids, offsets and status in pinned host memory; H2D, kernels
+    # and D2H overlap chunk by chunk.  It moves 1.7 x as many bytes up as down, so the D2H link bounds it.
     if wl_name == "cfg3":
-        t4, o4 = make_corpus("english", 1250000, 4, workers)
+        link = pcie_rates(torch, dev)
+        hb = jtokkit_amd.HostBuffer(n_bytes)
+        hb.array[:] = text
+        be = new_batch(enc)
+        be.set_option(jtokkit_amd._native.JTK_OPT_HOST_CHUNK_BYTES, 64 << 20)
+        be.set_option(jtokkit_amd._native.JTK_OPT_CHUNKS_IN_FLIGHT, 3)
+        be.encode_host(hb.array, doc_off, ordinary=args.ordinary, to_host=True)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            be.encode_host(hb.array, doc_off, ordinary=args.ordinary, to_host=True)
+        dte = (time.perf_counter() - t0) / 2
+        res = be.host_result()
+        nt_e = int(res.tok_off[-1])
+        ver = None
+        if not args.no_verify:
+            ver = verify_host_sample("cl100k_base", res, text, doc_off, 3000, args.ordinary)
+        up = 4 * nt_e + 12 * (n_docs + 1)
+        out["end_to_end_cfg3"] = {
+            "workload": "the headline corpus: pinned host buffers in -> token ids, offsets and status in pinned host memory, every step",
+            "value": round(n_bytes / dte / 1e6, 1), "unit": "MB/s of input", "ms_per_step": round(dte * 1e3, 2),
+            "bytes_host_to_device": int(n_bytes + 8 * (n_docs + 1)), "bytes_device_to_host": int(up),
+            "pcie_GBps_measured": {k: round(v, 1) for k, v in link.items()},
+            "d2h_link_fraction": round(up / dte / 1e9 / link["d2h"], 3), "h2d_link_fraction": round(n_bytes / dte / 1e9 / link["h2d"], 3),
+            "path": "jtk_host_alloc input, JTK_ENCODE_TO_HOST (64 MiB chunks, 3 in flight), result read in place",
+            "verified": None if ver is None else "%d sampled documents == CPU oracle" % ver}
+        hb.close()
+        be.close()
+
+    # ---- configs[3] on ONE GPU: the N = 1 point of the 10M-doc strong-scaling curve (the N > 1 lines of this bench time the same
+    # corpus sharded over N GPUs by contiguous document ranges), chunked through the same scratch sets
+    if wl_name == "cfg3" and not args.no_cfg4:
+        dev_arrays.clear()                                            # (the headline corpus leaves the device: 10 GB of text follow)
+        del d_text, d_off
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        t4, o4 = make_corpus("english", 10000000, 4, workers)
+        gen_s = time.perf_counter() - t0
         d_t4, d_o4 = torch.from_numpy(t4).to(dev), torch.from_numpy(o4).to(dev)
         b4 = new_batch(enc)
-        dt4, _, nt4 = time_encode(torch, [b4], d_t4, d_o4, len(o4) - 1, len(t4), 3, 1, args.ordinary)
-        ns = None if args.no_verify else verify_sample("cl100k_base", b4, t4, o4, 5000, args.ordinary, seed=7)
-        out["cfg4_shard"] = {"workload": "one 8-GPU shard of configs[3]: 1.25M English docs (~1 KB each) on 1xMI355X",
-                             "bytes": len(t4), "tokens": int(nt4), "value": rate(len(t4), dt4, 3), "unit": "MB/s",
-                             "ms_per_step": round(dt4 / 3 * 1e3, 3),
-                             "verified": None if ns is None else "%d sampled documents == CPU oracle" % ns}
+        dt4, st4, nt4 = time_encode(torch, [b4], d_t4, d_o4, len(o4) - 1, len(t4), 3, 1, args.ordinary)
+        ns = None if args.no_verify else verify_sample("cl100k_base", b4, t4, o4, 10000, args.ordinary, seed=7)
+        out["cfg4_full"] = {"workload": "configs[3] on one GPU: cl100k_base, 10M English docs (~1 KB each), %d chunks of ~%d MiB" % (
+                                len(batch_chunks(b4, len(t4), args)), args.chunk_mb or 1024),
+                            "bytes": len(t4), "tokens": int(nt4), "value": rate(len(t4), dt4, 3), "unit": "MB/s",
+                            "ms_per_step": round(dt4 / 3 * 1e3, 3), "kernel_ms": {k: round(v, 3) for k, v in st4.items()},
+                            "corpus_generation_s": round(gen_s, 1),
+                            "verified": None if ns is None else "%d sampled documents == CPU oracle" % ns}
         b4.close()
         del d_t4, d_o4, t4, o4
+        torch.cuda.empty_cache()
 
     # ---- the reference's per-call shape (one Encoding.encode call per document from a pool of threads,
     # benchmark/.../AbstractMultiThreadedBenchmark.java:35-45) through the C ABI, driven by native threads

@@ -69,8 +69,13 @@ enum {
                                      have fewer launches and kernel tails; env JTK_CHUNK_BYTES).  Scratch: ~30 bytes per
                                      byte of chunk per set */
     JTK_OPT_CHUNKS_IN_FLIGHT = 2, /* scratch sets / streams, 1..4 (default 2; env JTK_CHUNKS_IN_FLIGHT) */
-    JTK_OPT_HOST_CHUNK_BYTES = 3  /* ... host input (default 32 MiB: the copy of one chunk overlaps the kernels of another;
+    JTK_OPT_HOST_CHUNK_BYTES = 3, /* ... host input (default 32 MiB: the copy of one chunk overlaps the kernels of another;
                                      env JTK_HOST_CHUNK_BYTES) */
+    JTK_OPT_REUSE_CHUNK_PLAN = 4  /* 1: jtk_batch_encode_device keeps the chunk plan of the last batch while it is handed the same
+                                     offsets array again (same pointer and counts: a step loop) -- no plan kernel, no host
+                                     synchronisation in the call.  The caller promises not to change those offsets in place
+                                     (if it does: JTK_ERR_INVALID_ARGUMENT as the batch's worst status, never wrong tokens).
+                                     Default 0 */
 };
 
 typedef struct jtk_encoding jtk_encoding;

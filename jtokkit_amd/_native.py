@@ -31,6 +31,7 @@ JTK_ENCODE_TO_HOST = 8
 JTK_OPT_CHUNK_BYTES = 1
 JTK_OPT_CHUNKS_IN_FLIGHT = 2
 JTK_OPT_HOST_CHUNK_BYTES = 3
+JTK_OPT_REUSE_CHUNK_PLAN = 4
 
 # every symbol include/jtokkit_amd.h declares: (restype, argtypes)
 _p = C.c_void_p

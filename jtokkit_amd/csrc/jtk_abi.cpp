@@ -105,6 +105,13 @@ struct jtk_batch {
     int64_t* host_plan = nullptr;    // pinned
     size_t host_plan_cap = 0;
     std::vector<int64_t> chunk_doc, chunk_off;
+    // JTK_OPT_REUSE_CHUNK_PLAN: the plan of the last device-resident batch is kept while the same offsets array (same pointer, counts)
+    // is encoded again -- a step loop --, which saves the plan kernel and the call's only synchronisation.  The caller promises
+    // not to change the offsets in place; if it does, the chunks' first and last documents no longer sit where the plan says and
+    // k_mark_docs reports JTK_ERR_INVALID_ARGUMENT -- never a wrong answer.
+    const int64_t* plan_doc_off = nullptr;
+    int64_t plan_docs = -1, plan_bytes = -1, plan_chunk_bytes = -1;
+    bool reuse_plan = false;             // JTK_OPT_REUSE_CHUNK_PLAN
     // results streamed to pinned host memory (JTK_ENCODE_TO_HOST)
     int32_t* h_tokens = nullptr; size_t h_tokens_cap = 0;
     int64_t* h_tok_off = nullptr; size_t h_tok_off_cap = 0;
@@ -344,6 +351,10 @@ int jtk_batch_set_option(jtk_batch* b, int option, int64_t value) {
         case JTK_OPT_CHUNKS_IN_FLIGHT:
             if (value < 1 || value > MAX_SETS) return fail(JTK_ERR_INVALID_ARGUMENT, "chunks in flight: 1..4");
             b->n_sets = (int)value;
+            return JTK_OK;
+        case JTK_OPT_REUSE_CHUNK_PLAN:
+            b->reuse_plan = value != 0;
+            b->plan_doc_off = nullptr;
             return JTK_OK;
         default: return fail(JTK_ERR_INVALID_ARGUMENT, "unknown option");
     }
@@ -663,6 +674,9 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : b->stream;
     // chunk plan: a batch of up to one chunk needs none; a larger one reads the chunk boundaries from the offsets (the one
     // place where this call waits for the work queued on `s` before it)
+    const bool same_plan = b->reuse_plan && b->plan_doc_off == d_doc_off && b->plan_docs == n_docs && b->plan_bytes == n_bytes && b->plan_chunk_bytes == b->chunk_bytes &&
+                           b->chunk_doc.size() >= 2 && b->chunk_doc.back() == n_docs && b->chunk_off.back() == n_bytes;
+    if (!same_plan) {
     b->chunk_doc.assign(1, 0);
     b->chunk_off.assign(1, 0);
     if (n_bytes > b->chunk_bytes + b->chunk_bytes / 4 && n_docs > 1) {
@@ -687,7 +701,10 @@ int jtk_batch_encode_device(jtk_batch* b, const uint8_t* d_utf8, const int64_t* 
     }
     b->chunk_doc.push_back(n_docs);
     b->chunk_off.push_back(n_bytes);
+    b->plan_doc_off = d_doc_off; b->plan_docs = n_docs; b->plan_bytes = n_bytes; b->plan_chunk_bytes = b->chunk_bytes;
+    }
     int rc = run_job(b, d_utf8, nullptr, d_doc_off, n_docs, n_bytes, flags, s, false);
+    if (rc != JTK_OK) b->plan_doc_off = nullptr;
     if (rc != JTK_OK) return rc;
     if (n_tokens) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -706,6 +723,7 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
     if (n_bytes >= (int64_t)1 << 37) return fail(JTK_ERR_INVALID_ARGUMENT, "batch too large (128 GiB of text per call at most)");
     // chunk plan (and the check of the offsets) in one pass
     const int64_t cb = b->host_chunk_bytes < b->chunk_bytes ? b->host_chunk_bytes : b->chunk_bytes;
+    b->plan_doc_off = nullptr;
     b->chunk_doc.assign(1, 0);
     b->chunk_off.assign(1, 0);
     {
@@ -766,6 +784,7 @@ int jtk_batch_encode_pieces(jtk_batch* b, const uint8_t* utf8, const int64_t* do
         }
     }
     const int64_t cb = b->host_chunk_bytes < b->chunk_bytes ? b->host_chunk_bytes : b->chunk_bytes;
+    b->plan_doc_off = nullptr;
     b->chunk_doc.assign(1, 0);
     b->chunk_off.assign(1, 0);
     {

@@ -44,6 +44,11 @@ class Comm:
         self._h = h
         self.world, self.rank = world, rank
 
+    def comm_world(self):
+        """jtk_comm_world: the number of ranks of the RCCL communicator itself."""
+        from . import _native as N
+        return int(N.lib().jtk_comm_world(self._h))
+
     def stitch(self, d_tok_off_ptr, n_docs, d_global_off_ptr, stream):
         """Queued on `stream`: all-gather of the shard totals, base, global offsets.  Returns device pointers (totals, base)."""
         from . import _native as N

@@ -890,3 +890,24 @@ def test_service_tickets_polled_by_spinning(tmp_path):
                         os.path.join(ROOT, "jtokkit_amd", "data", "cl100k_base.tiktoken"), "16", "200000", "64"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0 and "spin ok: 200000 documents" in p.stdout, (p.returncode, p.stdout[-300:], p.stderr[-300:])
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 path (configs[3]: the corpus sharded by contiguous document ranges, one rank per process, the offset
+    stitch after every step, max-over-ranks timing, per-rank verification against the oracle) launched the way the driver
+    launches it -- two ranks by torch.distributed.run -- but with both ranks on this box's one GPU (JTK_BENCH_REHEARSAL=1: the
+    totals travel over gloo instead of RCCL)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, JTK_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--docs", "200000",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["value"] > 0 and r["config"]["docs"] == 200000
+    assert len(r["per_rank"]["MBps"]) == 2 and sum(r["per_rank"]["bytes"]) == r["config"]["bytes"]
+    assert "== CPU oracle" in r["verified"]
