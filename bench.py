@@ -60,7 +60,11 @@ def make_corpus(kind, n_docs, seed0, workers):
     else:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
-            parts = pool.map(_gen_shard, jobs, chunksize=1)
+            parts = []
+            for k, part in enumerate(pool.imap(_gen_shard, jobs, chunksize=1)):
+                parts.append(part)
+                if len(jobs) > 20 and (k + 1) % 10 == 0:
+                    print("[bench] corpus shards %d / %d" % (k + 1, len(jobs)), file=sys.stderr, flush=True)
     total = sum(len(t) for t, _ in parts)
     text = np.empty(total, dtype=np.uint8)
     doc_off = np.empty(n_docs + 1, dtype=np.int64)
@@ -344,6 +348,7 @@ def main():
             args.encoding, "10M" if total_docs == 10000000 else str(total_docs), world)
         wl_key, scaling = "cfg2", "strong"
     n_docs, n_bytes = len(doc_off) - 1, int(doc_off[-1])
+    log("corpus ready: %d docs, %.1f MB" % (n_docs, n_bytes / 1e6))
     d_text = torch.from_numpy(text).to(dev)
     d_off = torch.from_numpy(doc_off).to(dev)
     enc = jtokkit_amd.get_encoding(args.encoding, device=local_rank)
@@ -378,6 +383,7 @@ def main():
     dt, stage_ms, nt = time_encode(torch, [batch], d_text, d_off, n_docs, n_bytes, args.steps, args.warmup, args.ordinary,
                                    world, dist, after)
 
+    log("timed region done: %.3f s for %d steps" % (dt, args.steps))
     # max over ranks, sums of bytes
     stats = torch.tensor([dt, float(n_bytes), float(nt), float(n_docs)], dtype=torch.float64,
                          device=torch.device("cpu") if rehearsal else dev)
@@ -460,6 +466,7 @@ def main():
         out.update(sub)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            log("CPU baseline")
             out["cpu_baseline"] = cpu_baseline(args.encoding, text, doc_off, max_threads=args.cpu_threads, ordinary=args.ordinary)
         print(json.dumps(out), flush=True)
     batch.close()
@@ -511,6 +518,14 @@ def batch_chunks(batch, n_bytes, args):
     return list(range((n_bytes + cb - 1) // cb))
 
 
+def log(msg):
+    """Progress on stderr (a long run must not look hung; stdout carries the one JSON line)."""
+    print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def pcie_rates(torch, dev, mb=1024):
     """Pinned host <-> device copy rates of this box (one direction at a time), for the end-to-end record."""
     h = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
@@ -538,6 +553,7 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev
         return round(nb * steps / dt / 1e6, 1)
 
     # ---- configs[1]: 100k English docs, HBM-resident; one batch alone and two batches in flight (round 1's headline mode)
+    log("sub-records: configs[1]")
     if wl_name != "cfg2":
         t2, o2 = make_corpus("english", 100000, 2, workers)
         d_t2, d_o2 = torch.from_numpy(t2).to(dev), torch.from_numpy(o2).to(dev)
@@ -593,6 +609,7 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev
         del d_t2, d_o2
 
     # ---- configs[4]: r50k_base then p50k_base back to back on the 1M-doc corpus (rank-table swap)
+    log("sub-records: configs[4]")
     if wl_name == "cfg3":
         encs = {n: jtokkit_amd.get_encoding(n, device=0) for n in ("r50k_base", "p50k_base")}
         bs = {n: new_batch(e) for n, e in encs.items()}
@@ -625,6 +642,7 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev
 
     # ---- end to end on the headline workload: pinned host text in -> token ids, offsets and status in pinned host memory; H2D, kernels
     # and D2H overlap chunk by chunk.  It moves 1.7 x as many bytes up as down, so the D2H link bounds it.
+    log("sub-records: end to end on the headline corpus")
     if wl_name == "cfg3":
         link = pcie_rates(torch, dev)
         hb = jtokkit_amd.HostBuffer(n_bytes)
@@ -660,9 +678,11 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev
         dev_arrays.clear()                                            # (the headline corpus leaves the device: 10 GB of text follow)
         del d_text, d_off
         torch.cuda.empty_cache()
+        log("sub-records: configs[3] on one GPU (generating 10M documents)")
         t0 = time.perf_counter()
         t4, o4 = make_corpus("english", 10000000, 4, workers)
         gen_s = time.perf_counter() - t0
+        log("10M documents generated in %.0f s" % gen_s)
         d_t4, d_o4 = torch.from_numpy(t4).to(dev), torch.from_numpy(o4).to(dev)
         b4 = new_batch(enc)
         dt4, st4, nt4 = time_encode(torch, [b4], d_t4, d_o4, len(o4) - 1, len(t4), 3, 1, args.ordinary)
@@ -680,10 +700,12 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev
     # ---- the reference's per-call shape (one Encoding.encode call per document from a pool of threads,
     # benchmark/.../AbstractMultiThreadedBenchmark.java:35-45) through the C ABI, driven by native threads
     if wl_name == "cfg3":
+        log("sub-records: per-call shapes")
         out["per_call"] = per_call_record(args)
 
     # ---- vocabulary stress: documents of uniformly random rank-table entries (the lookups miss the caches realistically)
     if wl_name != "vocab":
+        log("sub-records: vocabulary stress")
         tv, ov = vocab_stress_corpus(100000)
         d_tv, d_ov = torch.from_numpy(tv).to(dev), torch.from_numpy(ov).to(dev)
         bv = new_batch(enc)
