@@ -672,6 +672,35 @@ def subrecords(out, torch, dev, args, jtokkit_amd, new_batch, text, doc_off, dev
         hb.close()
         be.close()
 
+        # ---- Encoding.encode(text, maxTokens) over the first 200k documents of the headline corpus: the early exit (leading bytes
+        # only) beside encoding every document whole and truncating afterwards.  Host buffers in, host arrays out, both ways.
+        log("sub-records: maxTokens early exit")
+        nd_m, mx = min(n_docs, 200000), 10
+        off_m = doc_off[:nd_m + 1]
+        text_m = text[:int(off_m[-1])]
+        bm = new_batch(enc)
+        bm.encode_max_tokens(text_m, off_m, mx, ordinary=True)             # (buffers grow on the first call)
+        t0 = time.perf_counter()
+        tk_m, kept_m, flag_m, st_m = bm.encode_max_tokens(text_m, off_m, mx, ordinary=True)
+        dt_early = time.perf_counter() - t0
+        bm.encode_host(text_m, off_m, ordinary=True)
+        t0 = time.perf_counter()
+        bm.encode_host(text_m, off_m, ordinary=True)
+        kept_w, flag_w = bm.truncate(mx)
+        res_w = bm.fetch()
+        dt_whole = time.perf_counter() - t0
+        assert np.array_equal(kept_m, kept_w) and np.array_equal(flag_m, flag_w) and (st_m == 0).all()
+        pick = np.random.default_rng(3).choice(nd_m, 5000, replace=False)
+        for d in pick:
+            assert np.array_equal(tk_m[d, :kept_m[d]], res_w.tokens[res_w.tok_off[d]:res_w.tok_off[d] + kept_w[d]])
+        out["max_tokens"] = {
+            "workload": "encodeOrdinary(text, %d) for the first %d documents of the headline corpus (%.0f MB)" % (mx, nd_m, len(text_m) / 1e6),
+            "early_exit_s": round(dt_early, 4), "whole_then_truncate_s": round(dt_whole, 4), "speedup": round(dt_whole / dt_early, 1),
+            "docs_per_s": round(nd_m / dt_early), "unit": "documents/s (early exit)",
+            "verified": "kept counts and truncated flags of all documents, ids of 5000 sampled documents == encoding whole then truncating"}
+        del res_w
+        bm.close()
+
     # ---- configs[3] on ONE GPU: the N = 1 point of the 10M-doc strong-scaling curve (the N > 1 lines of this bench time the same
     # corpus sharded over N GPUs by contiguous document ranges), chunked through the same scratch sets
     if wl_name == "cfg3" and not args.no_cfg4:

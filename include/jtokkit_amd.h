@@ -197,6 +197,15 @@ int jtk_batch_truncate(jtk_batch* b, int64_t max_tokens);
 int jtk_batch_fetch_truncated(jtk_batch* b, int64_t* kept, uint8_t* truncated);           /* [n_docs] each, may be NULL */
 int jtk_batch_device_truncated(jtk_batch* b, const int64_t** d_kept, const uint8_t** d_truncated);
 
+/* Encoding.encode(text, maxTokens) / encodeOrdinary(text, maxTokens) for every document WITHOUT encoding the documents whole
+ * (the reference stops matching at maxTokens, GptBytePairEncoding.java:83-88): leading bytes of each document are encoded
+ * (8 per wanted token + 64, 4x more for the documents that turn out to need it) and a result is taken once it is certain to be the
+ * head of the full token list.  Host buffers.  tokens: [n_docs * max_tokens], document d's ids at tokens + d * max_tokens;
+ * kept[d] ids are valid; truncated[d] (may be NULL) = EncodingResult.isTruncated(); status[d] (may be NULL) is JTK_OK or
+ * JTK_ERR_UNSUPPORTED_SPECIAL.  flags: JTK_ENCODE_ORDINARY or 0. */
+int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs, uint32_t flags,
+                                int64_t max_tokens, int32_t* tokens, int64_t* kept, uint8_t* truncated, int32_t* status);
+
 /* ---- batch decode on the device ---------------------------------------------------------------------
  * Replaces a loop of Encoding.decodeBytes(List<Integer>) (GptBytePairEncoding.java:137-151, 302-314; special-token
  * ids decode to their literals, :308-311) over n_seqs token lists: all ids back to back in `ids`, list q occupying

@@ -63,6 +63,7 @@ SIGNATURES = {
     "jtk_batch_set_profiling": (C.c_int, [_p, C.c_int]),
     "jtk_batch_kernel_times": (C.c_int, [_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "jtk_batch_truncate": (C.c_int, [_p, _i64]),
+    "jtk_batch_encode_max_tokens": (C.c_int, [_p, _p, _p, _i64, C.c_uint32, _i64, _p, _p, _p, _p]),
     "jtk_batch_fetch_truncated": (C.c_int, [_p, _p, _p]),
     "jtk_batch_device_truncated": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p)]),
     "jtk_batch_decode": (C.c_int, [_p, _p, _p, _i64, C.POINTER(_i64)]),

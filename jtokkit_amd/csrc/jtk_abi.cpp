@@ -10,6 +10,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <thread>
+#include <chrono>
 
 #include "../../include/jtokkit_amd.h"
 #include "jtk_kernels.h"
@@ -1047,14 +1049,18 @@ int jtk_decode(const jtk_encoding* enc, const int32_t* ids, int64_t n, uint8_t* 
     return JTK_OK;
 }
 
-// UTF-16 length of well-formed UTF-8 (String.length())
-static int64_t utf16_len(const uint8_t* s, int64_t n) {
-    int64_t k = 0;
-    for (int64_t i = 0; i < n; i++) if ((s[i] & 0xC0) != 0x80) k += (s[i] >= 0xF0) ? 2 : 1;
-    return k;
-}
-
 }  // extern "C"
+
+// Host loops over many documents (the gather of the prefixes and the decisions of the maxTokens early exit): slices of
+// [0, n) on up to 8 threads when there is enough to share out.
+template <class F> static void host_slices(size_t n, F&& fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+    if (n < 16384 || nt == 1) { fn(0, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++) th.emplace_back([&, k] { fn((int)k, n * k / nt, n * (k + 1) / nt); });
+    for (auto& t : th) t.join();
+}
 
 // Encoding.encode(text, maxTokens) from the full token list of `text` (GptBytePairEncoding.java:90-100): the first
 // min(maxTokens, nt) tokens, backed off until decode(tokens) is a prefix of the text.  head: at least that many leading
@@ -1062,27 +1068,34 @@ static int64_t utf16_len(const uint8_t* s, int64_t n) {
 int64_t jtk_max_tokens_backoff(const jtk_encoding* enc, const uint8_t* utf8, int64_t len, const int32_t* head, int64_t nt,
                                int64_t max_tokens, int* truncated) {
     int64_t keep = nt < max_tokens ? nt : max_tokens;
-    std::vector<int64_t> cum((size_t)keep + 1, 0);
+    static thread_local std::vector<int64_t> cum;
+    cum.assign((size_t)keep + 1, 0);
     for (int64_t k = 0; k < keep; k++) cum[(size_t)k + 1] = cum[(size_t)k] + enc->tok_len[(size_t)head[(size_t)k]];
-    const int64_t text16 = utf16_len(utf8, len);
     if (truncated) *truncated = 0;
+    // does text[from:] hold more than `k` UTF-16 units?  (looks at the first few bytes only: the document may be long)
+    auto more_units_than = [&](int64_t from, int64_t k) {
+        int64_t u = 0;
+        for (int64_t i = from; i < len; i++)
+            if ((utf8[i] & 0xC0) != 0x80) { u += (utf8[i] >= 0xF0) ? 2 : 1; if (u > k) return true; }
+        return false;
+    };
     for (;; keep--) {
         // decode(tokens) is the byte prefix [0, nb) of the text.  text.startsWith(decoded) holds when
         // nb is a code-point boundary, or when the cut character decodes to one U+FFFD and the text
-        // has U+FFFD there.
+        // has U+FFFD there.  truncated = text.length() > decoded.length(), both in UTF-16 units: the units before the
+        // cut are common to both, so only the text from the cut on is counted.
         const int64_t nb = cum[(size_t)keep];
         const bool boundary = (nb == len) || ((utf8[nb] & 0xC0) != 0x80);
-        int64_t dec16;
-        bool starts;
-        if (boundary) { dec16 = utf16_len(utf8, nb); starts = true; }
+        bool starts, longer;
+        if (boundary) { starts = true; longer = more_units_than(nb, 0); }
         else {
             int64_t c = nb;
             while (c > 0 && (utf8[c] & 0xC0) == 0x80) c--;
-            dec16 = utf16_len(utf8, c) + 1;
             starts = (c + 2 < len) && utf8[c] == 0xEF && utf8[c + 1] == 0xBF && utf8[c + 2] == 0xBD;
+            longer = more_units_than(c, 1);                       // the decoded text ends in one U+FFFD for the cut character
         }
         if (starts) {
-            if (truncated) *truncated = text16 > dec16;
+            if (truncated) *truncated = longer;
             break;
         }
         if (keep == 0) break;
@@ -1098,6 +1111,23 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     if (truncated) *truncated = 0;
     if (n_tokens) *n_tokens = 0;
     if (!utf8) return JTK_OK;                                    // text == null -> empty result
+    if (max_tokens >= 0) {
+        // encode(text, maxTokens): the leading bytes only (jtk_batch_encode_max_tokens below)
+        const int64_t off2[2] = {0, len};
+        std::vector<int32_t> head((size_t)((max_tokens < len ? max_tokens : len) + 1));
+        int64_t keep = 0; uint8_t tr = 0; int32_t st = 0;
+        int rc = jtk_batch_encode_max_tokens(b, utf8, off2, 1, flags & JTK_ENCODE_ORDINARY, max_tokens, head.data(), &keep, &tr, &st);
+        if (rc != JTK_OK) return rc;
+        if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
+        if (st != JTK_OK) return fail(st, "document could not be encoded");
+        if (truncated) *truncated = tr;
+        if (n_tokens) *n_tokens = keep;
+        if (tokens) {
+            if (tokens_cap < keep) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
+            if (keep > 0) memcpy(tokens, head.data(), (size_t)keep * 4);
+        }
+        return JTK_OK;
+    }
     const int64_t off[2] = {0, len};
     int64_t nt = 0;
     int rc = jtk_batch_encode(b, utf8, off, 1, flags, &nt);
@@ -1106,26 +1136,184 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     HIP_TRY(hipMemcpy(&st, b->status.p, 4, hipMemcpyDeviceToHost));
     if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
     if (st != JTK_OK) return fail(st, "document could not be encoded");
-    if (max_tokens < 0) {
-        if (n_tokens) *n_tokens = nt;
-        if (tokens) {
-            if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
-            if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
-        }
-        return JTK_OK;
-    }
-    // encode(text, maxTokens): pieces encode independently, so the list before the back-off of
-    // GptBytePairEncoding.java:90-100 is the first min(maxTokens, total) tokens of the full result.
-    int64_t keep = nt < max_tokens ? nt : max_tokens;
-    std::vector<int32_t> head((size_t)(keep > 0 ? keep : 1));
-    if (keep > 0) HIP_TRY(hipMemcpy(head.data(), b->tokens.p, (size_t)keep * 4, hipMemcpyDeviceToHost));
-    int tr = 0;
-    keep = jtk_max_tokens_backoff(b->enc, utf8, len, head.data(), nt, max_tokens, &tr);
-    if (truncated) *truncated = tr;
-    if (n_tokens) *n_tokens = keep;
+    if (n_tokens) *n_tokens = nt;
     if (tokens) {
-        if (tokens_cap < keep) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
-        if (keep > 0) memcpy(tokens, head.data(), (size_t)keep * 4);
+        if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
+        if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
+    }
+    return JTK_OK;
+}
+
+// A byte that may begin a white-space character: the ASCII ones, and the lead bytes of U+0085/U+00A0 (C2), U+1680 (E1),
+// U+2000..U+205F (E2) and U+3000 (E3).  Conservative on purpose: it only ever makes the early exit below look further.
+static inline bool maybe_space(uint8_t c) { return (c >= 0x09 && c <= 0x0D) || c == 0x20 || c == 0xC2 || c == 0xE1 || c == 0xE2 || c == 0xE3; }
+
+// Encoding.encode(text, maxTokens) for every document, without encoding the documents whole.  The reference stops matching
+// once maxTokens tokens exist (GptBytePairEncoding.java:83-88); here each document's leading P bytes are encoded (P = 8 bytes
+// per wanted token + 64 to begin with), and the result is taken when it is certain to be the head of the document's full token
+// list: that is the tokens before a piece start q that (a) lies at least 16 bytes before the cut -- every look-ahead of the
+// patterns (a contraction, the character after a white-space run) is shorter -- and (b) does not sit inside a white-space run
+// that might reach the cut (`\s*[\r\n]+` and `\s+(?!\S)` look to the END of the run): text[q] is no white space, or it is one
+// ASCII white-space character followed by something else.  Pieces before q are then matched exactly as in the whole text and
+// pieces encode independently.  Documents whose prefix holds fewer than maxTokens such tokens go round again with 4x the bytes.
+int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, int64_t n_docs, uint32_t flags,
+                                int64_t max_tokens, int32_t* tokens, int64_t* kept, uint8_t* truncated, int32_t* status) {
+    if (!b || n_docs < 0 || !doc_off || max_tokens < 0 || !kept || (max_tokens > 0 && n_docs > 0 && !tokens))
+        return fail(JTK_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (doc_off[0] != 0) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off[0] must be 0");
+    for (int64_t d = 0; d < n_docs; d++)
+        if (doc_off[d + 1] < doc_off[d]) return fail(JTK_ERR_INVALID_ARGUMENT, "doc_off must be non-decreasing");
+    const int64_t n_bytes = doc_off[n_docs];
+    if (n_bytes > 0 && !utf8) return fail(JTK_ERR_INVALID_ARGUMENT, "utf8 is NULL");
+    const jtk_encoding* enc = b->enc;
+    std::vector<uint8_t> special((size_t)(n_docs > 0 ? n_docs : 1), 0);
+    if (!(flags & JTK_ENCODE_ORDINARY)) {                            // text.contains(special) looks at the whole document (:52-56)
+        for (auto& sp : enc->host.specials) {
+            const std::string& lit = sp.first;
+            if (lit.empty() || (int64_t)lit.size() > n_bytes) continue;
+            const uint8_t* p = utf8;
+            const uint8_t* endp = utf8 + n_bytes;
+            while (p < endp) {
+                const void* hit = memmem(p, (size_t)(endp - p), lit.data(), lit.size());
+                if (!hit) break;
+                const int64_t pos = (const uint8_t*)hit - utf8;
+                const int64_t d = (std::upper_bound(doc_off, doc_off + n_docs + 1, pos) - doc_off) - 1;
+                if (d >= 0 && d < n_docs && pos + (int64_t)lit.size() <= doc_off[d + 1]) special[(size_t)d] = 1;
+                p = (const uint8_t*)hit + 1;
+            }
+        }
+    }
+    std::vector<int64_t> active;
+    active.reserve((size_t)n_docs);
+    for (int64_t d = 0; d < n_docs; d++) {
+        kept[d] = 0;
+        if (truncated) truncated[d] = 0;
+        if (status) status[d] = special[(size_t)d] ? JTK_ERR_UNSUPPORTED_SPECIAL : JTK_OK;
+        if (special[(size_t)d]) continue;
+        const int64_t len = doc_off[d + 1] - doc_off[d];
+        if (len == 0 || max_tokens == 0) {
+            int tr = 0;
+            jtk_max_tokens_backoff(enc, utf8 + doc_off[d], len, nullptr, 0, 0, &tr);
+            if (truncated) truncated[d] = (uint8_t)tr;
+            continue;
+        }
+        active.push_back(d);
+    }
+    const int64_t margin = 16;
+    const int64_t cb = b->host_chunk_bytes < b->chunk_bytes ? b->host_chunk_bytes : b->chunk_bytes;   // a group stays one chunk
+    int64_t P = max_tokens > ((int64_t)1 << 40) ? (int64_t)1 << 44 : 8 * max_tokens + 64;
+    std::vector<uint8_t> gtext;
+    std::vector<int64_t> goff, next_active;
+    std::vector<uint64_t> mask;
+    const bool trace = getenv("JTK_MAXTOK_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_gather = 0, t_enc = 0, t_dec = 0, t_mask = 0;
+    while (!active.empty()) {
+        next_active.clear();
+        size_t a0 = 0;
+        while (a0 < active.size()) {
+            // one group: as many prefixes as fit one chunk
+            size_t a1 = a0;
+            int64_t gbytes = 0;
+            goff.assign(1, 0);
+            while (a1 < active.size()) {
+                const int64_t d = active[a1], len = doc_off[d + 1] - doc_off[d];
+                int64_t p = len < P ? len : P;
+                if (p > cb) p = len;                                 // past one host chunk the document goes whole, and alone
+                if (a1 > a0 && gbytes + p > cb) break;
+                gbytes += p;
+                goff.push_back(gbytes);
+                a1++;
+            }
+            double t0 = now();
+            gtext.resize((size_t)gbytes + 1);
+            host_slices(a1 - a0, [&](int, size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; i++)
+                    memcpy(gtext.data() + goff[i], utf8 + doc_off[active[a0 + i]], (size_t)(goff[i + 1] - goff[i]));
+            });
+            const int64_t ng = (int64_t)(a1 - a0);
+            int64_t nt = 0;
+            const int64_t save_host_chunk = b->host_chunk_bytes;
+            if (gbytes > cb) b->host_chunk_bytes = gbytes;           // a single document above the host chunk size: still one chunk
+            double t1 = now(); t_gather += t1 - t0;
+            int rc = jtk_batch_encode(b, gtext.data(), goff.data(), ng, JTK_ENCODE_ORDINARY | JTK_ENCODE_TO_HOST, &nt);
+            b->host_chunk_bytes = save_host_chunk;
+            double t2 = now(); t_enc += t2 - t1;
+            if (rc != JTK_OK) return rc;
+            if (b->chunk_doc.size() != 2) {
+                // longer than a device chunk: no single piece mask; such a document is encoded whole
+                const int32_t* toks = b->r_tokens; const int64_t* toff = b->r_tok_off;
+                for (size_t a = a0; a < a1; a++) {
+                    const int64_t d = active[a], len = doc_off[d + 1] - doc_off[d], i = (int64_t)(a - a0);
+                    if (goff[i + 1] - goff[i] != len) return fail(JTK_ERR_INVALID_ARGUMENT, "max-tokens prefix spans device chunks");
+                    int tr = 0;
+                    const int64_t k = jtk_max_tokens_backoff(enc, utf8 + doc_off[d], len, toks + toff[i], toff[i + 1] - toff[i], max_tokens, &tr);
+                    if (k > 0) memcpy(tokens + d * max_tokens, toks + toff[i], (size_t)k * 4);
+                    kept[d] = k;
+                    if (truncated) truncated[d] = (uint8_t)tr;
+                }
+                a0 = a1;
+                continue;
+            }
+            const int32_t* toks = b->r_tokens; const int64_t* toff = b->r_tok_off; const int32_t* st = b->r_status;
+            const size_t n_words = (size_t)((gbytes + 1 + 63) / 64);
+            mask.resize(n_words);
+            {
+                double tm = now();
+                HIP_TRY(hipMemcpy(mask.data(), b->set[0].piecemask.p, n_words * 8, hipMemcpyDeviceToHost));
+                t_mask += now() - tm;
+            }
+            std::vector<int64_t> again[8];
+            host_slices(a1 - a0, [&](int slice, size_t lo, size_t hi) {
+                for (size_t ii = lo; ii < hi; ii++) {
+                    const int64_t i = (int64_t)ii, d = active[a0 + ii], len = doc_off[d + 1] - doc_off[d];
+                    const int64_t p = goff[i + 1] - goff[i], t0 = toff[i], n = toff[i + 1] - t0;
+                    if (st[i] != JTK_OK) { if (status) status[d] = st[i]; continue; }
+                    int64_t k = -1;
+                    if (p == len) k = n;
+                    else {
+                        // the last safe piece start at or before p - margin
+                        const uint8_t* t = gtext.data() + goff[i];
+                        int64_t q = 0;
+                        for (int64_t pos = goff[i] + p - margin; pos > goff[i]; ) {
+                            uint64_t w = mask[(size_t)(pos >> 6)];
+                            const int sh = (int)(pos & 63);
+                            w = sh == 63 ? w : (w & ((2ull << sh) - 1));                 // bits 0..sh
+                            const int64_t wbase = pos & ~(int64_t)63;
+                            bool found = false;
+                            while (w) {
+                                const int bit = 63 - __builtin_clzll(w);
+                                const int64_t cand = wbase + bit;
+                                if (cand <= goff[i]) { w = 0; break; }
+                                const uint8_t c0 = t[cand - goff[i]], c1 = t[cand - goff[i] + 1];
+                                if (!maybe_space(c0) || (c0 < 0x80 && !maybe_space(c1))) { q = cand - goff[i]; found = true; break; }
+                                w &= ~(1ull << bit);
+                            }
+                            if (found) break;
+                            pos = wbase - 1;
+                        }
+                        if (q > 0) {
+                            int64_t cum = 0, kk = 0;
+                            while (kk < n && kk < max_tokens && cum < q) cum += enc->tok_len[(size_t)toks[t0 + kk]], kk++;
+                            if (cum <= q && kk >= max_tokens) k = kk;                   // maxTokens tokens, all before q
+                        }
+                    }
+                    if (k < 0) { again[slice].push_back(d); continue; }
+                    int tr = 0;
+                    const int64_t keep = jtk_max_tokens_backoff(enc, utf8 + doc_off[d], len, toks + t0, k, max_tokens, &tr);
+                    if (keep > 0) memcpy(tokens + d * max_tokens, toks + t0, (size_t)keep * 4);
+                    kept[d] = keep;
+                    if (truncated) truncated[d] = (uint8_t)tr;
+                }
+            });
+            for (auto& v : again) next_active.insert(next_active.end(), v.begin(), v.end());
+            t_dec += now() - t2;
+            a0 = a1;
+        }
+        if (trace) fprintf(stderr, "[max_tokens] P=%lld docs=%zu -> %zu again; gather %.2f encode %.2f mask %.2f decide(incl. mask) %.2f ms\n",
+                           (long long)P, active.size(), next_active.size(), t_gather, t_enc, t_mask, t_dec);
+        active.swap(next_active);
+        P = P > ((int64_t)1 << 40) ? P : P * 4;
     }
     return JTK_OK;
 }

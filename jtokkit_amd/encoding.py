@@ -197,6 +197,20 @@ class Batch:
         return a.value, b.value, c.value
 
     # ---- maxTokens for the whole batch (device) ---------------------------------------------------------
+    def encode_max_tokens(self, text_u8, doc_off, max_tokens, ordinary=False):
+        """jtk_batch_encode_max_tokens: (tokens [n_docs, max_tokens], kept [n_docs], truncated [n_docs], status [n_docs])."""
+        text_u8 = np.ascontiguousarray(text_u8, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+        nd, mt = len(doc_off) - 1, max(0, int(max_tokens))
+        toks = np.zeros((nd, mt), dtype=np.int32)
+        kept = np.zeros(nd, dtype=np.int64)
+        flag = np.zeros(nd, dtype=np.uint8)
+        status = np.zeros(nd, dtype=np.int32)
+        _check(N.lib().jtk_batch_encode_max_tokens(self._h, text_u8.ctypes.data, doc_off.ctypes.data, nd,
+                                                   N.JTK_ENCODE_ORDINARY if ordinary else 0, mt, toks.ctypes.data,
+                                                   kept.ctypes.data, flag.ctypes.data, status.ctypes.data))
+        return toks, kept, flag, status
+
     def truncate(self, max_tokens):
         """Encoding.encode(text, maxTokens) for every document of the last encode -> (kept int64[n], truncated bool[n])."""
         _check(N.lib().jtk_batch_truncate(self._h, int(max_tokens)))
@@ -400,20 +414,17 @@ class HipEncoding:
         return np.array(pb, dtype=np.int64), np.array(pe, dtype=np.int64)
 
     def encode_batch_max_tokens(self, texts, max_tokens, ordinary=False):
-        """List of str/bytes -> list of EncodingResult, as Encoding.encode(text, maxTokens) gives for each."""
+        """List of str/bytes -> list of EncodingResult, as Encoding.encode(text, maxTokens) gives for each.  Only the leading
+        bytes of each document are encoded (jtk_batch_encode_max_tokens), as the reference stops matching at maxTokens."""
         bs = [t if isinstance(t, (bytes, bytearray)) else t.encode("utf-8") for t in texts]
         doc_off = np.zeros(len(bs) + 1, dtype=np.int64)
         if bs:
             np.cumsum([len(x) for x in bs], out=doc_off[1:])
         text = np.frombuffer(b"".join(bs), dtype=np.uint8) if doc_off[-1] else np.zeros(0, dtype=np.uint8)
-        b = self._b()
-        b.encode_host(text, doc_off, ordinary)
-        res = b.fetch()
-        if len(res.status) and res.status.min() < 0:
-            _check(int(res.status.min()))
-        kept, flag = b.truncate(max_tokens)
-        return [EncodingResult(res.tokens[res.tok_off[d]:res.tok_off[d] + kept[d]].tolist(), bool(flag[d]))
-                for d in range(len(bs))]
+        toks, kept, flag, status = self._b().encode_max_tokens(text, doc_off, max_tokens, ordinary)
+        if len(status) and status.min() < 0:
+            _check(int(status.min()))
+        return [EncodingResult(toks[d, :kept[d]].tolist(), bool(flag[d])) for d in range(len(bs))]
 
     def count_tokens_batch(self, texts, ordinary=False):
         """Encoding.countTokens / countTokensOrdinary for every text, one device call, no token ids written."""

@@ -347,6 +347,40 @@ def test_batch_max_tokens_fuzz(jt):
             assert r.get_tokens() == exp_toks and r.is_truncated() == exp_tr
 
 
+def test_batch_max_tokens_long_documents_early_exit(jt):
+    """Documents far longer than the limit needs (the early exit encodes their leading bytes only): prose, mixed scripts,
+    code, white-space runs with line breaks placed around every prefix length the early exit tries (8 * max + 64, then
+    x4), digits, contractions, specials.  == oracle encode(text, max) on the whole document, every encoding."""
+    from jtokkit_amd import corpus
+    rng = random.Random(11)
+    docs = []
+    for text, off in (corpus.english(40, seed=3), corpus.mixed(60, seed=4)):
+        docs += [bytes(text[off[i]:off[i + 1]]).decode("utf-8") for i in range(len(off) - 1)]
+    ws = [" ", "  ", "\n", " \n", "\n\n ", "\t", "\r\n", "\u00a0", "\u2003", "\u3000", " \n \n  \n ", "   "]
+    for mx in (1, 4, 10, 50):
+        for grow in (1, 4, 16):
+            cut = (8 * mx + 64) * grow
+            for _ in range(6):
+                head = rc.random_text(rng, 400)[:cut - rng.randint(0, 40)]
+                run = "".join(rng.choice(ws) for _ in range(rng.randint(1, 30)))
+                docs.append(head + run + rc.random_text(rng, 200) + "they'll we've 1234567 " * 20)
+    docs += [" " * 5000 + "x", "\n" * 3000 + "end", "a" * 9000, "1234567890" * 700, ("it's " * 40 + "\n") * 30,
+             "word " * 2000, "한국어 텍스트 " * 600, "x" + " \n" * 2500 + "y" * 50, "hello <|endoftext|> " * 300]
+    for name in NAMES:
+        enc = jt.get_encoding(name)
+        o = oracle_lib.get(name)
+        for mx in (0, 1, 4, 10, 50, 700):
+            got = enc.encode_batch_max_tokens(docs, mx, ordinary=True)
+            for t, r in zip(docs, got):
+                exp_toks, exp_tr = o.encode_ordinary(t, mx)
+                assert r.get_tokens() == exp_toks and r.is_truncated() == exp_tr, (name, mx, t[:80])
+    enc = jt.get_encoding("cl100k_base")
+    with pytest.raises(Exception, match="special"):
+        enc.encode_batch_max_tokens(["x" * 5000 + "<|endoftext|>"], 3)
+    assert enc.encode_batch_max_tokens(["x" * 5000 + "<|endoftext|>"], 3, ordinary=True)[0].get_tokens() == \
+        oracle_lib.get("cl100k_base").encode_ordinary("x" * 5000 + "<|endoftext|>", 3)[0]
+
+
 def _train_tiny_bpe(corpus_bytes, n_merges, seed=0):
     """A small byte-pair table trained the textbook way: all 256 bytes (ranks shuffled, as in the real tables where
     rank != byte value), then n_merges merges of the most frequent adjacent pair inside whitespace-split words."""
