@@ -300,20 +300,41 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 		}
 	}
 
-	/** Encoding.encode(text, maxTokens) / encodeOrdinary(text, maxTokens) for every text: one encode pass + jtk_batch_truncate. */
+	/**
+	 * Encoding.encode(text, maxTokens) / encodeOrdinary(text, maxTokens) for every text.  Only the leading bytes of each text are
+	 * encoded (jtk_batch_encode_max_tokens), as the reference stops matching at maxTokens (GptBytePairEncoding.java:83-88).
+	 */
 	public List<EncodingResult> encodeBatch(final List<String> texts, final boolean ordinary, final int maxTokens) {
 		if (hostPattern != null) {
 			return encodeBatchPieces(texts, ordinary, maxTokens);
 		}
-		final long[] off = new long[texts.size() + 1];
+		final int limit = Math.max(maxTokens, 0);
+		final int n = texts.size();
+		final long[] off = new long[n + 1];
 		final ByteBuffer buf = pack(texts, off);
 		final long b = borrowBatch();
 		try {
-			final BatchResult r = nativeEncodeBatch(b, buf, off, ordinary ? 1 : 0);
-			final long[] kept = new long[texts.size()];
-			final boolean[] truncated = new boolean[texts.size()];
-			nativeTruncateBatch(b, maxTokens, kept, truncated);            // GptBytePairEncoding.java:90-100 on the device
-			return toResults(r, kept, truncated);
+			// (ids of at most n * limit entries: a limit that makes this exceed an int[] falls back to encoding whole)
+			if ((long) n * limit > Integer.MAX_VALUE - 8) {
+				final BatchResult r = nativeEncodeBatch(b, buf, off, ordinary ? 1 : 0);
+				final long[] kept = new long[n];
+				final boolean[] truncated = new boolean[n];
+				nativeTruncateBatch(b, limit, kept, truncated);            // GptBytePairEncoding.java:90-100 on the device
+				return toResults(r, kept, truncated);
+			}
+			final int[] ids = new int[n * limit];
+			final long[] kept = new long[n];
+			final boolean[] truncated = new boolean[n];
+			nativeEncodeBatchMaxTokens(b, buf, off, ordinary ? 1 : 0, limit, ids, kept, truncated);
+			final List<EncodingResult> out = new ArrayList<>(n);
+			for (int d = 0; d < n; d++) {
+				final List<Integer> toks = new ArrayList<>((int) kept[d]);
+				for (int i = 0; i < kept[d]; i++) {
+					toks.add(ids[d * limit + i]);
+				}
+				out.add(new EncodingResult(toks, truncated[d]));
+			}
+			return out;
 		} finally {
 			returnBatch(b);
 		}
@@ -483,6 +504,7 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 	private static native BatchResult nativeEncodeBatchPieces(long batch, ByteBuffer utf8, long[] docOff, long[] pieceBegin,
 			long[] pieceEnd, int flags);
 	private static native void nativeTruncateBatch(long batch, long maxTokens, long[] kept, boolean[] truncated);
+	private static native void nativeEncodeBatchMaxTokens(long batch, ByteBuffer utf8, long[] docOff, int flags, int maxTokens, int[] ids, long[] kept, boolean[] truncated);
 	private static native byte[][] nativeDecodeBatch(long batch, int[] ids, long[] seqOff);
 	private static native byte[] nativeDecode(long encoding, int[] ids);
 	private static native ByteBuffer nativeHostAlloc(long bytes);

@@ -201,6 +201,32 @@ JNIEXPORT void JNICALL FN(nativeTruncateBatch)(JNIEnv* env, jclass c, jlong batc
     if (rc != JTK_OK) throw_for(env, rc);
 }
 
+/* Encoding.encode(text, maxTokens) for every document WITHOUT encoding the documents whole (the reference stops matching at
+ * maxTokens, GptBytePairEncoding.java:83-88): ids[d * maxTokens ..] hold kept[d] ids of document d */
+JNIEXPORT void JNICALL FN(nativeEncodeBatchMaxTokens)(JNIEnv* env, jclass c, jlong batch, jobject utf8, jlongArray docOff, jint flags,
+                                                       jint maxTokens, jintArray ids, jlongArray kept, jbooleanArray truncated) {
+    (void)c;
+    const uint8_t* text = (const uint8_t*)(*env)->GetDirectBufferAddress(env, utf8);
+    jsize n1 = (*env)->GetArrayLength(env, docOff);
+    const size_t n = (size_t)(n1 - 1), mt = (size_t)(maxTokens > 0 ? maxTokens : 0);
+    jlong* off = (*env)->GetLongArrayElements(env, docOff, NULL);
+    int32_t* tk = (int32_t*)malloc((n * mt + 1) * sizeof(int32_t));
+    int64_t* k = (int64_t*)malloc((n + 1) * sizeof(int64_t));
+    uint8_t* t = (uint8_t*)malloc(n + 1);
+    int32_t* st = (int32_t*)malloc((n + 1) * sizeof(int32_t));
+    int rc = jtk_batch_encode_max_tokens(BATCH(batch), text, (const int64_t*)off, (int64_t)n, (uint32_t)flags & JTK_ENCODE_ORDINARY,
+                                         (int64_t)mt, tk, k, t, st);
+    (*env)->ReleaseLongArrayElements(env, docOff, off, JNI_ABORT);
+    for (size_t d = 0; d < n && rc == JTK_OK; d++) if (st[d] != JTK_OK) rc = st[d];          /* :52-56 special token in the text */
+    if (rc == JTK_OK) {
+        (*env)->SetIntArrayRegion(env, ids, 0, (jsize)(n * mt), (const jint*)tk);
+        (*env)->SetLongArrayRegion(env, kept, 0, (jsize)n, (const jlong*)k);
+        (*env)->SetBooleanArrayRegion(env, truncated, 0, (jsize)n, (const jboolean*)t);
+    }
+    free(tk); free(k); free(t); free(st);
+    if (rc != JTK_OK) throw_for(env, rc);
+}
+
 /* a loop of Encoding.decodeBytes over many token lists: one device pass */
 JNIEXPORT jobjectArray JNICALL FN(nativeDecodeBatch)(JNIEnv* env, jclass c, jlong batch, jintArray ids, jlongArray seqOff) {
     (void)c;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes (one counter group per run; --pmc is never combined with trace domains) over a serial bench run:
-#   bash tools/r02_pmc.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>/summary.csv
-set -e
+#   bash tools/pmc.sh <tag> [bench args...]   -> gpurun_out/pmc_<tag>/summary.csv
+set +e
 tag=$1; shift
 root=$(pwd)
 out=$root/gpurun_out/pmc_$tag
@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 pass() {
   name=$1; shift
-  rocprofv3 --pmc "$@" -d $out/$name -o c --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-subrecords --serial --gen-workers 1 $BENCH_ARGS > $out/$name.log 2>&1
+  timeout -k 5 ${PMC_PASS_TIMEOUT:-240} rocprofv3 --pmc "$@" -d $out/$name -o c --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-subrecords --serial --gen-workers 1 $BENCH_ARGS > $out/$name.log 2>&1
   echo "pass $name done"
 }
 BENCH_ARGS="$*"
@@ -17,8 +17,10 @@ if [ -z "$PMC_SQ_ONLY" ]; then   # PMC_SQ_ONLY=1: instruction / wait counters on
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 fi
+if [ -z "$PMC_HBM_ONLY" ]; then   # PMC_HBM_ONLY=1: the two HBM passes alone
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
+fi
 if [ -n "$PMC_CACHES" ]; then   # PMC_CACHES=1: also the cache counters (slow on large batches)
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum

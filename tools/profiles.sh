@@ -1,11 +1,11 @@
 #!/bin/bash
 # Profiles of the headline run, committed under profiles/ (run through gpurun from the repo root):
-#   bash tools/r02_profiles.sh <tag>
+#   bash tools/profiles.sh <tag>
 # 1. rocprofv3 --kernel-trace --stats of `python bench.py --no-subrecords --no-cpu-baseline` (the headline alone: the
 #    default command adds the sub-records' workloads to the same process)
 # 2. PMC passes (one counter group per run, never combined with trace domains) of a one-chunk slice of the headline corpus
 #    (250k docs = 1 GiB = one launch of every kernel, as in the headline's chunks) and of configs[1]
-set -e
+set +e
 tag=$1
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
@@ -17,9 +17,9 @@ fi
 cd $root
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 echo "kernel trace done"
-bash tools/r02_pmc.sh ${tag}_cfg3 --workload cfg3 --docs 250000 > $out/pmc_cfg3.log 2>&1
+bash tools/pmc.sh ${tag}_cfg3 --workload cfg3 --docs 250000 > $out/pmc_cfg3.log 2>&1
 echo "pmc cfg3 done"
-bash tools/r02_pmc.sh ${tag}_cfg2 --workload cfg2 > $out/pmc_cfg2.log 2>&1
+bash tools/pmc.sh ${tag}_cfg2 --workload cfg2 > $out/pmc_cfg2.log 2>&1
 cp gpurun_out/pmc_${tag}_cfg3/summary.csv $out/pmc_cfg3_per_kernel.csv
 cp gpurun_out/pmc_${tag}_cfg2/summary.csv $out/pmc_cfg2_per_kernel.csv
 python3 - <<PY
