@@ -287,8 +287,19 @@ class HipEncoding:
         self._batch = None
         self._svc = None
         self._svc_lock = threading.Lock()
+        # close() against per-call methods in progress on other threads: calls are counted, close() waits for them to leave
+        # and later ones raise instead of touching freed handles
+        self._life = threading.Condition()
+        self._calls = 0
+        self._closed = False
 
     def close(self):
+        life = getattr(self, "_life", None)
+        if life is not None:
+            with life:
+                self._closed = True
+                while self._calls:
+                    life.wait()
         if self._batch is not None:
             self._batch.close()
             self._batch = None
@@ -333,9 +344,19 @@ class HipEncoding:
         out = np.empty(cap, dtype=np.int32)
         nt = C.c_int64(0)
         tr = C.c_int(0)
-        _check(N.lib().jtk_service_encode(self._service(), bytes(b), len(b), N.JTK_ENCODE_ORDINARY if ordinary else 0,
-                                          -1 if max_tokens is None else max(0, int(max_tokens)), out.ctypes.data, cap,
-                                          C.byref(nt), C.byref(tr)))
+        with self._life:
+            if self._closed:
+                raise RuntimeError("encoding is closed")
+            self._calls += 1
+        try:
+            _check(N.lib().jtk_service_encode(self._service(), bytes(b), len(b), N.JTK_ENCODE_ORDINARY if ordinary else 0,
+                                              -1 if max_tokens is None else max(0, int(max_tokens)), out.ctypes.data, cap,
+                                              C.byref(nt), C.byref(tr)))
+        finally:
+            with self._life:
+                self._calls -= 1
+                if not self._calls:
+                    self._life.notify_all()
         return out[:nt.value].tolist(), bool(tr.value)
 
     def encode(self, text, max_tokens=None):                       # Encoding.java:29,61

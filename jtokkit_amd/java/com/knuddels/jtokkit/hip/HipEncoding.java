@@ -68,21 +68,44 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 		return new HipEncoding(name, 1, tiktokenFileBytes, specialLiterals, specialIds, device, pattern);
 	}
 
-	private long borrowBatch() {
+	/**
+	 * close() against calls in progress: every method that goes down to the native handles holds the read side for the
+	 * duration of the call, close() takes the write side before it destroys them -- it waits for the calls that are inside and
+	 * later ones fail with IllegalStateException instead of touching freed memory.
+	 */
+	private final java.util.concurrent.locks.ReentrantReadWriteLock life = new java.util.concurrent.locks.ReentrantReadWriteLock();
+
+	private void enter() {
+		life.readLock().lock();
 		if (closed) {
+			life.readLock().unlock();
 			throw new IllegalStateException("encoding is closed");
 		}
+	}
+
+	private void leave() {
+		life.readLock().unlock();
+	}
+
+	private long borrowBatch() {
+		enter();
 		final Long b = idleBatches.poll();
 		if (b != null) {
 			return b;
 		}
-		final long created = nativeBatchCreate(encodingHandle);
-		allBatches.add(created);
-		return created;
+		try {
+			final long created = nativeBatchCreate(encodingHandle);
+			allBatches.add(created);
+			return created;
+		} catch (final RuntimeException e) {
+			leave();
+			throw e;
+		}
 	}
 
 	private void returnBatch(final long b) {
 		idleBatches.add(b);
+		leave();
 	}
 
 	public static HipEncoding cl100kBase(final int device) {
@@ -158,15 +181,20 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 			f.complete(encodeInternal(text, flags, -1).getTokens());
 			return f;
 		}
-		final long ticket = nativeServiceSubmit(serviceHandle, text.getBytes(StandardCharsets.UTF_8), flags);
-		synchronized (inFlight) {
-			inFlight.add(new Pending(ticket, f));
-			if (completer == null) {
-				completer = new Thread(this::completeLoop, "jtokkit-amd-completer");
-				completer.setDaemon(true);
-				completer.start();
+		enter();
+		try {
+			final long ticket = nativeServiceSubmit(serviceHandle, text.getBytes(StandardCharsets.UTF_8), flags);
+			synchronized (inFlight) {
+				inFlight.add(new Pending(ticket, f));
+				if (completer == null) {
+					completer = new Thread(this::completeLoop, "jtokkit-amd-completer");
+					completer.setDaemon(true);
+					completer.start();
+				}
+				inFlight.notifyAll();
 			}
-			inFlight.notifyAll();
+		} finally {
+			leave();
 		}
 		return f;
 	}
@@ -198,17 +226,29 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 						return;
 					}
 				}
-				p = inFlight.poll();
 			}
+			// (the read side is taken BEFORE the ticket leaves the queue: close() waits for an empty queue, then for the write
+			// side, so the service outlives every wait)
+			life.readLock().lock();
 			try {
-				final int[] ids = nativeServiceWait(serviceHandle, p.ticket);      // throws what encode() would
-				final List<Integer> out = new ArrayList<>(ids.length);
-				for (final int id : ids) {
-					out.add(id);
+				synchronized (inFlight) {
+					p = inFlight.poll();
 				}
-				p.future.complete(out);
-			} catch (final RuntimeException e) {
-				p.future.completeExceptionally(e);
+				if (p == null) {
+					continue;
+				}
+				try {
+					final int[] ids = nativeServiceWait(serviceHandle, p.ticket);      // throws what encode() would
+					final List<Integer> out = new ArrayList<>(ids.length);
+					for (final int id : ids) {
+						out.add(id);
+					}
+					p.future.complete(out);
+				} catch (final RuntimeException e) {
+					p.future.completeExceptionally(e);
+				}
+			} finally {
+				life.readLock().unlock();
 			}
 		}
 	}
@@ -234,7 +274,12 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 		for (int i = 0; i < ids.length; i++) {
 			ids[i] = tokens.get(i);
 		}
-		return nativeDecode(encodingHandle, ids);   // JTK_ERR_UNKNOWN_TOKEN -> IllegalArgumentException
+		enter();
+		try {
+			return nativeDecode(encodingHandle, ids);   // JTK_ERR_UNKNOWN_TOKEN -> IllegalArgumentException
+		} finally {
+			leave();
+		}
 	}
 
 	@Override
@@ -252,7 +297,13 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 		if (hostPattern != null) {
 			return encodeBatchPieces(Collections.singletonList(text), (flags & 1) != 0, maxTokens).get(0);
 		}
-		final int[] ids = nativeServiceEncode(serviceHandle, utf8, flags, maxTokens, truncated);
+		final int[] ids;
+		enter();
+		try {
+			ids = nativeServiceEncode(serviceHandle, utf8, flags, maxTokens, truncated);
+		} finally {
+			leave();
+		}
 		final List<Integer> out = new ArrayList<>(ids.length);
 		for (final int id : ids) {
 			out.add(id);
@@ -481,13 +532,18 @@ public final class HipEncoding implements Encoding, AutoCloseable {
 				}
 			}
 		}
-		nativeServiceDestroy(serviceHandle);
-		for (final long b : allBatches) {
-			nativeBatchDestroy(b);
+		life.writeLock().lock();                                           // calls in progress leave first
+		try {
+			nativeServiceDestroy(serviceHandle);
+			for (final long b : allBatches) {
+				nativeBatchDestroy(b);
+			}
+			allBatches.clear();
+			idleBatches.clear();
+			nativeDestroy(encodingHandle);
+		} finally {
+			life.writeLock().unlock();
 		}
-		allBatches.clear();
-		idleBatches.clear();
-		nativeDestroy(encodingHandle);
 	}
 
 	private static native long nativeCreate(String name, int patternKind, byte[] tiktoken, String[] specialLiterals,
