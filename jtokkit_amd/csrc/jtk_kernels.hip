@@ -796,8 +796,10 @@ __device__ __forceinline__ M lean_steps(uint32_t* id, uint32_t* rk, M alive, con
         uint32_t r2 = jtk_pair_match2(v2.x, v2.y, v2.z, v2.w, klo2, kt2);
         const bool more1 = want1 && r1 == JTK_RANK_NONE && (v0.y & JTK_PAIR_OVERFLOW) != 0u;
         const bool more2 = want2 && r2 == JTK_RANK_NONE && (v2.y & JTK_PAIR_OVERFLOW) != 0u;
-        if (__ballot(more1 || more2)) {
-            // the secondary buckets, for the lanes that need them (the others re-read bucket lines they just had)
+        if (more1 || more2) {
+            // the secondary buckets, by the lanes that need one only (r03: with every lane taking part -- the others re-reading
+            // their primary line -- the kernel was 2-3 % slower; with all four loads of a step issued together 20 % slower).
+            // Both loads sit in one branch so that they are in flight together; a lane that needs one re-reads its other primary.
             const uint32_t h1 = more1 ? jtk_reduce32(jtk_pair_mix2(m1), nb) : jtk_reduce32(m1, nb);
             const uint32_t h2 = more2 ? jtk_reduce32(jtk_pair_mix2(m2), nb) : jtk_reduce32(m2, nb);
             const uint4 v1 = *reinterpret_cast<const uint4*>(bk + ((size_t)h1 << 4));

@@ -3,7 +3,7 @@
 # after-the-clock check (experiment builds may give wrong tokens)
 for lib in default $(ls tools/variants/*.so 2>/dev/null); do
   if [ "$lib" != default ]; then export JTOKKIT_AMD_LIB=$PWD/$lib; fi
-  for wl in "cfg2" "cfg3 --docs 250000"; do
+  for wl in "cfg2" "cfg3 --docs 250000" "vocab"; do
     python bench.py --workload $wl --steps 6 --warmup 2 --no-subrecords --no-cpu-baseline --no-verify 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
