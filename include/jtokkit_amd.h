@@ -97,7 +97,7 @@ int jtk_device_count(void);
  * GptBytePairEncoding.java:81-83 is honoured for pieces of any length: for tables in which merging a token's bytes
  * reproduces the token (every table trained by byte-pair merging; the three shipped ones) it is a pure shortcut, for others
  * the unreproducible entries get a lookup of their own and the exact intra-piece cuts are switched off.
- * Special tokens: at most 8 literals of 1..32 bytes (any first byte), ids < 131071 + 2^20. */
+ * Special tokens: any number of literals of any length >= 1 (any first byte), ids < 131071 + 2^20. */
 int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tiktoken, size_t tiktoken_len,
                         const char* const* special_literals, const int32_t* special_ids, int n_specials,
                         int device, jtk_encoding** out);

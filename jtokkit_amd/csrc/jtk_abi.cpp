@@ -59,7 +59,7 @@ int jtk_fail_msg(int code, const std::string& msg) { return fail(code, msg); }  
 struct jtk_encoding {
     JtkHostTables host;
     int device = 0;
-    DevBuf uc1, uc2, brank, pairs, tok8, tok16, bprank, bpbits, bpcum, bpranks, pairin, dec_off, dec_blob, longtok, longblob;
+    DevBuf uc1, uc2, brank, pairs, tok8, tok16, bprank, bpbits, bpcum, bpranks, pairin, dec_off, dec_blob, longtok, longblob, specials;
     uint32_t n_ids_table = 0;        // ids 0 .. n_ids_table-1 have an entry in the decode table (incl. special tokens)
     JtkDeviceTables dt;
     std::vector<uint32_t> tok_len;   // byte length per id (0 = absent), for the maxTokens back-off
@@ -170,7 +170,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     for (int i = 0; i < n_specials; i++) {
         const size_t l = strlen(special_literals[i]);
         if (l < 1 || l > JTK_SPECIAL_MAXLEN)
-            return fail(JTK_ERR_INVALID_ARGUMENT, "special-token literals must be 1..32 bytes long");
+            return fail(JTK_ERR_INVALID_ARGUMENT, "special-token literals must be 1..65535 bytes long");
         if (special_ids[i] < 0 || special_ids[i] > (int32_t)JTK_MAX_ID + (1 << 20))
             return fail(JTK_ERR_INVALID_ARGUMENT, "special-token id out of range");
     }
@@ -190,7 +190,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     }
     if (device < 0 || device >= ndev) { delete enc; return fail(JTK_ERR_INVALID_ARGUMENT, "device index out of range"); }
     enc->device = device;
-    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); enc->longtok.release(); enc->longblob.release(); delete enc; };
+    auto cleanup = [&]() { enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release(); enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release(); enc->dec_off.release(); enc->dec_blob.release(); enc->longtok.release(); enc->longblob.release(); enc->specials.release(); delete enc; };
 #define ENC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(JTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
     ENC_TRY(hipSetDevice(device));
     const size_t tok8_bytes = (enc->host.tok8.size() * sizeof(JtkTok8Slot) + 31) & ~(size_t)31;
@@ -233,7 +233,6 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
         ENC_TRY(hipMemcpy(enc->longtok.p, enc->host.long_tok.data(), enc->host.long_tok.size() * sizeof(JtkLongTokSlot), hipMemcpyHostToDevice));
         ENC_TRY(hipMemcpy(enc->longblob.p, enc->host.long_blob.data(), enc->host.long_blob.size(), hipMemcpyHostToDevice));
     }
-#undef ENC_TRY
     JtkDeviceTables& dt = enc->dt;
     memset(&dt, 0, sizeof(dt));
     dt.longtok.slots = (const JtkLongTokSlot*)enc->longtok.p;
@@ -262,11 +261,24 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     }
     dt.kind = pattern_kind;
     dt.n_specials = n_specials;
-    for (int i = 0; i < n_specials; i++) {
-        const size_t l = strlen(special_literals[i]);
-        dt.special_len[i] = (uint8_t)l;
-        memcpy(dt.special[i], special_literals[i], l);
+    {   // the literals for the device's text.contains check: offsets [n + 1] (u32), then the bytes
+        std::vector<uint32_t> off((size_t)n_specials + 1, 0);
+        std::vector<uint8_t> blob;
+        for (int i = 0; i < n_specials; i++) {
+            const size_t l = strlen(special_literals[i]);
+            blob.insert(blob.end(), (const uint8_t*)special_literals[i], (const uint8_t*)special_literals[i] + l);
+            off[(size_t)i + 1] = (uint32_t)blob.size();
+            const uint8_t f = (uint8_t)special_literals[i][0];
+            dt.special_first[f >> 5] |= 1u << (f & 31);
+        }
+        const size_t off_bytes = align_up(off.size() * 4, 16);
+        if (enc->specials.ensure(off_bytes + blob.size() + 16)) { cleanup(); return JTK_ERR_OUT_OF_MEMORY; }
+        ENC_TRY(hipMemcpy(enc->specials.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+        if (!blob.empty()) ENC_TRY(hipMemcpy((uint8_t*)enc->specials.p + off_bytes, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        dt.special_off = (const uint32_t*)enc->specials.p;
+        dt.special_blob = (const uint8_t*)enc->specials.p + off_bytes;
     }
+#undef ENC_TRY
     *out = enc;
     return JTK_OK;
 }
@@ -276,7 +288,7 @@ void jtk_encoding_destroy(jtk_encoding* enc) {
     (void)hipSetDevice(enc->device);
     enc->uc1.release(); enc->uc2.release(); enc->brank.release(); enc->pairs.release();
     enc->tok8.release(); enc->tok16.release(); enc->bprank.release(); enc->bpbits.release(); enc->bpcum.release(); enc->bpranks.release(); enc->pairin.release();
-    enc->dec_off.release(); enc->dec_blob.release(); enc->longtok.release(); enc->longblob.release();
+    enc->dec_off.release(); enc->dec_blob.release(); enc->longtok.release(); enc->longblob.release(); enc->specials.release();
     delete enc;
 }
 const char* jtk_encoding_name(const jtk_encoding* enc) { return enc ? enc->host.name.c_str() : ""; }

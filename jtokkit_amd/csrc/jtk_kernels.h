@@ -60,8 +60,8 @@
 #define JTK_LONG_CAP 8192        // wave-per-piece kernel, large bin
 #define JTK_GIANT_CAP (1 << 20)  // workgroup-per-piece kernel with parts in global scratch (= JTK_MAX_PIECE_BYTES)
 #define JTK_GIANT_CHUNK 256      // positions per cached chunk minimum
-#define JTK_MAX_SPECIALS 8
-#define JTK_SPECIAL_MAXLEN 32
+#define JTK_MAX_SPECIALS 65536           // special-token literals live in a device blob: the bounds are sanity checks only
+#define JTK_SPECIAL_MAXLEN 65535
 
 #define JTK_UC_LDS_STAGE1 4352    // capacity of the LDS copy of the Unicode class table (pretok_split)
 #define JTK_UC_LDS_STAGE2 2048
@@ -80,8 +80,9 @@ struct JtkDeviceTables {
     JtkLongTokTable longtok;         // table entries of > 16 bytes that merging does not reproduce (n == 0 for the shipped tables)
     int kind;
     int n_specials;
-    uint8_t special_len[JTK_MAX_SPECIALS];
-    uint8_t special[JTK_MAX_SPECIALS][JTK_SPECIAL_MAXLEN];
+    uint32_t special_first[8];       // bit b: some special-token literal starts with byte b
+    const uint8_t* special_blob;     // the literals back to back
+    const uint32_t* special_off;     // [n_specials + 1] into special_blob
 };
 
 // piece-list entry.  Resolved piece: token id (bits 0..16) | byte offset in the tile << 17.

@@ -95,10 +95,11 @@ __device__ int64_t find_doc(const JtkWork& w, int64_t p) {
 __device__ void special_check_at(const JtkWork& w, const JtkDeviceTables& t, int64_t p) {
     if (p < 0 || p >= w.n_bytes) return;
     for (int s = 0; s < t.n_specials; s++) {
-        const int len = t.special_len[s];
+        const uint32_t o = t.special_off[s];
+        const int len = (int)(t.special_off[s + 1] - o);
         if (p + len > w.n_bytes) continue;
         bool eq = true;
-        for (int j = 0; j < len && eq; j++) eq = (w.text[p + j] == t.special[s][j]);
+        for (int j = 0; j < len && eq; j++) eq = (w.text[p + j] == t.special_blob[o + j]);
         if (!eq) continue;
         const int64_t d = find_doc(w, p);
         if (d >= 0 && p + len <= w.doc_off[d + 1] - w.text_base) atomicMin(&w.status[d], -2 /* JTK_ERR_UNSUPPORTED_SPECIAL */);
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per
     const int64_t n = w.n_bytes;
     if (tid < 256) {
         uint32_t code = jtk_byte_code((uint32_t)tid, KIND == JTK_PAT_CL100K);
-        for (int q = 0; q < t.n_specials; q++) if (t.special[q][0] == (uint8_t)tid) code |= JTK_F_LT;
+        if ((t.special_first[tid >> 5] >> (tid & 31)) & 1u) code |= JTK_F_LT;
         if ((t.lead_letters[tid >> 5] >> (tid & 31)) & 1u) code |= JTK_F_ULL;
         s_tab[tid] = jtk_code4(code);
     }

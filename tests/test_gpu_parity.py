@@ -912,6 +912,59 @@ def test_hand_made_rank_table_with_unreproducible_entries(jt, kind):
     enc.close()
 
 
+def test_many_and_long_special_tokens(jt):
+    """GptBytePairEncodingParams accepts any special-token map (api/GptBytePairEncodingParams.java:36-46): 60 literals here,
+    some far longer than a tile edge matters for (up to 300 bytes), with arbitrary first bytes.  encode() refuses exactly the
+    documents that contain one (GptBytePairEncoding.java:52-56), in a batch, per call and with a token limit; the ids decode."""
+    import base64
+    from jtokkit_amd import corpus
+    ranks = _train_tiny_bpe(corpus.english(30, seed=6)[0].tobytes(), 300)
+    rng = random.Random(5)
+    specials = {}
+    for i in range(60):
+        n = rng.choice([1, 2, 5, 9, 31, 32, 33, 64, 100, 300])
+        lit = "".join(rng.choice("<|>[]~#@abcXYZ_0189é中") for _ in range(n)) + "#%d;" % i
+        specials[lit] = 200000 + i
+    enc = jt.new_custom_encoding("manyspecials", 1, ranks, specials)
+    data = b"\n".join(base64.b64encode(k) + b" " + str(v).encode() for k, v in sorted(ranks.items(), key=lambda kv: kv[1])) + b"\n"
+    o = oracle_lib.OracleEncoding("manyspecials", 1, data, specials)
+    lits = list(specials)
+    texts, has = [], []
+    for k in range(400):
+        body = rc.random_text(rng, rng.randint(0, 200))
+        if k % 3 == 0:
+            lit = rng.choice(lits)
+            cut = rng.randint(0, len(body))
+            texts.append(body[:cut] + lit + body[cut:]); has.append(True)
+        elif k % 3 == 1:
+            lit = rng.choice(lits)
+            texts.append(body + lit[:-1]); has.append(any(l in body + lit[:-1] for l in lits))     # all but the last character
+        else:
+            texts.append(body); has.append(any(l in body for l in lits))
+    b = enc.new_batch()
+    text = np.frombuffer("".join(texts).encode("utf-8"), dtype=np.uint8)
+    doc_off = np.zeros(len(texts) + 1, dtype=np.int64)
+    np.cumsum([len(t.encode("utf-8")) for t in texts], out=doc_off[1:])
+    b.encode_host(text, doc_off, ordinary=False)
+    res = b.fetch()
+    for d, (t, h) in enumerate(zip(texts, has)):
+        assert (res.status[d] == jt._native.JTK_ERR_UNSUPPORTED_SPECIAL) == h, (d, t[:60])
+        if not h:
+            assert res.tokens[res.tok_off[d]:res.tok_off[d + 1]].tolist() == o.encode(t)
+    toks, kept, flag, status = b.encode_max_tokens(text, doc_off, 5, ordinary=False)
+    assert [(s == jt._native.JTK_ERR_UNSUPPORTED_SPECIAL) for s in status] == has
+    b.close()
+    for t, h in list(zip(texts, has))[:40]:
+        if h:
+            with pytest.raises(jt.UnsupportedOperationError):
+                enc.encode(t)
+        else:
+            assert enc.encode(t) == o.encode(t)
+        assert enc.encode_ordinary(t) == o.encode_ordinary(t)
+    assert enc.decode([200000, 200059]) == lits[0] + lits[59]
+    enc.close()
+
+
 def test_service_tickets_polled_by_spinning(tmp_path):
     """The completion hand-off of the per-call service (jtk_service.cpp: one state word per ticket, published with an exchange):
     16 native threads, 200k documents, every ticket polled with jtk_service_done and collected -- and so freed -- the moment it
