@@ -14,7 +14,10 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,6 +67,9 @@ struct jtk_service {
     std::atomic<bool> stop{false};
     std::vector<std::thread> workers;
     std::atomic<int64_t> n_batches{0}, n_docs{0};
+    // JTK_SERVICE_TRACE=1: where a worker's time goes (ns, summed over workers), printed when the service is destroyed
+    bool trace = false;
+    std::atomic<int64_t> ns_idle{0}, ns_take{0}, ns_gather{0}, ns_encode{0}, ns_hand{0}, ns_wake{0}, n_wakes{0};
 };
 
 namespace {
@@ -84,8 +90,10 @@ void worker_main(jtk_service* s) {
     size_t doc_off_cap = 0;
     std::vector<jtk_ticket*> take, group;
     int create_rc = jtk_batch_create(s->enc, &b);
+    auto now = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
         take.clear();
+        const int64_t t_a = s->trace ? now() : 0;
         // everything that is queued right now (no timer: while this batch is on the device the next one piles up)
         while (s->pending.load(std::memory_order_acquire) == 0) {
             if (s->stop.load()) break;
@@ -93,6 +101,7 @@ void worker_main(jtk_service* s) {
             if (s->pending.load() == 0 && !s->stop.load()) futex_wait(&s->pending, 0);
             s->idle.fetch_sub(1);
         }
+        const int64_t t_b = s->trace ? now() : 0;
         {
             // (a document pushed after its shard was visited stays for the next round: `pending` is reduced by what was taken;
             // so does what exceeds max_docs / max_bytes: a device batch and its pinned staging are bounded)
@@ -118,6 +127,8 @@ void worker_main(jtk_service* s) {
             }
             continue;
         }
+        const int64_t t_c = s->trace ? now() : 0;
+        int64_t ns_g = 0, ns_e = 0;
         // encode() and encodeOrdinary() callers (and count-only ones) form separate device batches
         for (int pass = 0; pass < 4 && !take.empty(); pass++) {
             const uint32_t want = (pass & 1 ? JTK_ENCODE_ORDINARY : 0u) | (pass & 2 ? JTK_ENCODE_COUNT_ONLY : 0u);
@@ -149,11 +160,14 @@ void worker_main(jtk_service* s) {
             const int64_t* r_off = nullptr;
             const int32_t* r_st = nullptr;
             if (rc == JTK_OK) {
+                const int64_t t0 = s->trace ? now() : 0;
                 for (size_t i = 0; i < group.size(); i++)
                     if (group[i]->len) memcpy(h_text + doc_off[i], group[i]->utf8, (size_t)group[i]->len);
+                const int64_t t1 = s->trace ? now() : 0;
                 int64_t nt = 0;
                 rc = jtk_batch_encode(b, h_text, doc_off, (int64_t)group.size(), want | JTK_ENCODE_TO_HOST, &nt);
                 if (rc == JTK_OK) rc = jtk_batch_host_result(b, &r_tok, &r_off, &r_st);
+                if (s->trace) { ns_g += t1 - t0; ns_e += now() - t1; }
             }
             for (size_t i = 0; i < group.size(); i++) {
                 jtk_ticket* t = group[i];
@@ -172,9 +186,16 @@ void worker_main(jtk_service* s) {
             s->n_batches++;
             s->n_docs += (int64_t)group.size();
         }
+        const int64_t t_d = s->trace ? now() : 0;
+        int wakes = 0;
         for (jtk_ticket* t : take) {
             std::atomic<int>* st = &t->state;
-            if (st->exchange(1, std::memory_order_seq_cst) == 2) futex_wake(st, 1);    // (only the address is used after the exchange)
+            if (st->exchange(1, std::memory_order_seq_cst) == 2) { futex_wake(st, 1); wakes++; }    // (only the address is used after the exchange)
+        }
+        if (s->trace) {
+            const int64_t t_e = now();
+            s->ns_idle += t_b - t_a; s->ns_take += t_c - t_b; s->ns_gather += ns_g; s->ns_encode += ns_e;
+            s->ns_hand += (t_d - t_c) - ns_g - ns_e; s->ns_wake += t_e - t_d; s->n_wakes += wakes;
         }
     }
     if (h_text) jtk_host_free(h_text);
@@ -196,6 +217,7 @@ int jtk_service_create(const jtk_encoding* enc, int n_workers, jtk_service** out
     static std::atomic<unsigned> next_id{1};
     s->id = next_id.fetch_add(1);
     s->enc = enc;
+    s->trace = getenv("JTK_SERVICE_TRACE") != nullptr;
     s->device = jtk_encoding_device(enc);
     for (int i = 0; i < n_workers; i++) s->workers.emplace_back(worker_main, s);
     *out = s;
@@ -213,6 +235,13 @@ void jtk_service_destroy(jtk_service* s) {
     s->pending.fetch_add(1);                                     // wakes idle workers; they drain the queues and leave
     futex_wake(&s->pending, INT_MAX);
     for (auto& t : s->workers) t.join();
+    if (s->trace && s->n_batches.load() > 0) {
+        const double nb = (double)s->n_batches.load();
+        fprintf(stderr, "[service] %lld batches, %.1f docs each; per batch (us): idle %.1f take %.1f gather %.1f encode %.1f hand-out %.1f wake %.1f (%.1f wakes)\n",
+                (long long)s->n_batches.load(), (double)s->n_docs.load() / nb, s->ns_idle.load() / nb / 1e3, s->ns_take.load() / nb / 1e3,
+                s->ns_gather.load() / nb / 1e3, s->ns_encode.load() / nb / 1e3, s->ns_hand.load() / nb / 1e3, s->ns_wake.load() / nb / 1e3,
+                (double)s->n_wakes.load() / nb);
+    }
     delete s;
 }
 
