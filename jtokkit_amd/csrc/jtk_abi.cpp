@@ -762,9 +762,16 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
         if ((rc = ensure_pinned((void**)&b->h_in, &b->h_in_cap, total + 64, 0)) || (rc = b->in_text.ensure(total + 64))) return rc;
         memcpy(b->h_in, doc_off, ((size_t)n_docs + 1) * 8);
         if (n_bytes > 0) memcpy(b->h_in + off_text, utf8, (size_t)n_bytes);
+        static const bool zero_copy_in = getenv("JTK_TINY_ZERO_COPY_IN") != nullptr;
+        if (zero_copy_in) {
+            // experiment: the kernels read offsets and text straight from the pinned staging block over the link
+            rc = run_job(b, (const uint8_t*)b->h_in + off_text, nullptr, (const int64_t*)b->h_in, n_docs, n_bytes,
+                         flags & ~(uint32_t)JTK_ENCODE_TO_HOST, b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
+        } else {
         HIP_TRY(hipMemcpyAsync(b->in_text.p, b->h_in, total, hipMemcpyHostToDevice, b->stream));
         rc = run_job(b, (const uint8_t*)b->in_text.p + off_text, nullptr, (const int64_t*)b->in_text.p, n_docs, n_bytes,
                      flags & ~(uint32_t)JTK_ENCODE_TO_HOST, b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
+        }
     } else {
         if ((rc = b->in_text.ensure((size_t)n_bytes + 64)) || (rc = b->in_off.ensure(((size_t)n_docs + 1) * 8))) return rc;
         HIP_TRY(hipMemcpyAsync(b->in_off.p, doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
