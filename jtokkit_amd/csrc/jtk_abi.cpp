@@ -490,18 +490,29 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
     const size_t job_bytes = align_up(64 + ((size_t)n_chunks + 2) * 8, 16);
     const size_t off_status = job_bytes, off_tok_off = off_status + status_bytes;
     const size_t off_tokens = align_up(off_tok_off + ((size_t)n_docs + 1) * 8, 256);
-    if ((rc = b->out.ensure(off_tokens + ((size_t)n_bytes + 64) * 4))) return rc;
-    b->job.p = b->out.p;
-    b->status.p = (uint8_t*)b->out.p + off_status;
-    b->tok_off.p = (uint8_t*)b->out.p + off_tok_off;
-    b->tokens.p = (uint8_t*)b->out.p + off_tokens;
-    JtkResult* d_result = (JtkResult*)b->job.p;
-    int64_t* d_totals = (int64_t*)((uint8_t*)b->job.p + 64);       // [c]: tokens of the chunks before c
-    HIP_TRY(hipMemsetAsync(b->out.p, 0, off_tok_off, s));          // JtkResult, totals and status
     // a small single-chunk job (the per-call service's batches) copies its whole output block -- header, status, offsets and
     // the worst-case token range (one token per byte) -- right behind the kernels in ONE copy, instead of waiting for the
     // token count first: one host synchronisation and three copies less per batch
     const bool small_to_host = to_host && n_chunks == 1 && n_bytes <= SMALL_JOB_BYTES;
+    // r03: for the smallest of them (a per-call device batch) the output block IS pinned host memory -- pack, doc_offsets and the
+    // status atomics write over the link, and the copy up (a DMA of 14 us for 27 documents) is gone.  JTK_TINY_COPY_OUT=1: the copy.
+    static const bool copy_out_env = getenv("JTK_TINY_COPY_OUT") != nullptr;
+    const bool zero_copy_out = !copy_out_env && small_to_host && n_bytes <= TINY_JOB_BYTES && !h_text;
+    uint8_t* out_base;
+    if (zero_copy_out) {
+        if ((rc = ensure_pinned((void**)&b->h_small, &b->h_small_cap, off_tokens + ((size_t)n_bytes + 64) * 4 + 4096, 0))) return rc;
+        out_base = b->h_small;
+    } else {
+        if ((rc = b->out.ensure(off_tokens + ((size_t)n_bytes + 64) * 4))) return rc;
+        out_base = (uint8_t*)b->out.p;
+    }
+    b->job.p = out_base;
+    b->status.p = out_base + off_status;
+    b->tok_off.p = out_base + off_tok_off;
+    b->tokens.p = out_base + off_tokens;
+    JtkResult* d_result = (JtkResult*)b->job.p;
+    int64_t* d_totals = (int64_t*)((uint8_t*)b->job.p + 64);       // [c]: tokens of the chunks before c
+    HIP_TRY(hipMemsetAsync(out_base, 0, off_tok_off, s));          // JtkResult, totals and status
     if (to_host && !small_to_host) {
         if ((rc = ensure_pinned((void**)&b->h_tok_off, &b->h_tok_off_cap, ((size_t)n_docs + 1) * 8, 0)) ||
             (rc = ensure_pinned((void**)&b->h_status, &b->h_status_cap, (size_t)(n_docs > 0 ? n_docs : 1) * 4, 0)) ||
@@ -627,7 +638,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         jtk_launch_doc_offsets(w, cst);
         end();
         HIP_TRY(hipGetLastError());
-        if (small_to_host) {
+        if (small_to_host && !zero_copy_out) {
             // the whole answer in one copy: header, status, offsets and the worst-case token range (one token per byte)
             const size_t total = (flags & JTK_ENCODE_COUNT_ONLY) ? off_tokens : off_tokens + (size_t)n_bytes * 4;
             if ((rc = ensure_pinned((void**)&b->h_small, &b->h_small_cap, total + 4096, 0))) return rc;
@@ -762,16 +773,11 @@ int jtk_batch_encode(jtk_batch* b, const uint8_t* utf8, const int64_t* doc_off, 
         if ((rc = ensure_pinned((void**)&b->h_in, &b->h_in_cap, total + 64, 0)) || (rc = b->in_text.ensure(total + 64))) return rc;
         memcpy(b->h_in, doc_off, ((size_t)n_docs + 1) * 8);
         if (n_bytes > 0) memcpy(b->h_in + off_text, utf8, (size_t)n_bytes);
-        static const bool zero_copy_in = getenv("JTK_TINY_ZERO_COPY_IN") != nullptr;
-        if (zero_copy_in) {
-            // experiment: the kernels read offsets and text straight from the pinned staging block over the link
-            rc = run_job(b, (const uint8_t*)b->h_in + off_text, nullptr, (const int64_t*)b->h_in, n_docs, n_bytes,
-                         flags & ~(uint32_t)JTK_ENCODE_TO_HOST, b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
-        } else {
+        // (the other way round -- the kernels reading text and offsets from the pinned block over the link -- was 5 us slower:
+        // four kernels read the text)
         HIP_TRY(hipMemcpyAsync(b->in_text.p, b->h_in, total, hipMemcpyHostToDevice, b->stream));
         rc = run_job(b, (const uint8_t*)b->in_text.p + off_text, nullptr, (const int64_t*)b->in_text.p, n_docs, n_bytes,
                      flags & ~(uint32_t)JTK_ENCODE_TO_HOST, b->stream, (flags & JTK_ENCODE_TO_HOST) != 0);
-        }
     } else {
         if ((rc = b->in_text.ensure((size_t)n_bytes + 64)) || (rc = b->in_off.ensure(((size_t)n_docs + 1) * 8))) return rc;
         HIP_TRY(hipMemcpyAsync(b->in_off.p, doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
@@ -860,7 +866,7 @@ int jtk_batch_encode_pieces(jtk_batch* b, const uint8_t* utf8, const int64_t* do
     if (!special_docs.empty()) {
         const int32_t st = JTK_ERR_UNSUPPORTED_SPECIAL;
         for (int64_t d : special_docs) {
-            HIP_TRY(hipMemcpy((int32_t*)b->status.p + d, &st, 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy((int32_t*)b->status.p + d, &st, 4, hipMemcpyDefault));
             if (b->have_host_result) b->r_status[d] = st;
         }
         if (b->host_result->worst_status > st) b->host_result->worst_status = st;
@@ -892,12 +898,12 @@ int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* 
         if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
         if (nt > 0) {
             if (b->have_host_result) memcpy(tokens, b->r_tokens, (size_t)nt * 4);
-            else HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
+            else HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDefault));
         }
     }
-    if (tok_off) HIP_TRY(hipMemcpy(tok_off, b->tok_off.p, ((size_t)b->job_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (tok_off) HIP_TRY(hipMemcpy(tok_off, b->tok_off.p, ((size_t)b->job_docs + 1) * 8, hipMemcpyDefault));
     if (status && b->job_docs > 0)
-        HIP_TRY(hipMemcpy(status, b->status.p, (size_t)b->job_docs * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(status, b->status.p, (size_t)b->job_docs * 4, hipMemcpyDefault));
     return JTK_OK;
 }
 
@@ -1152,13 +1158,13 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     int rc = jtk_batch_encode(b, utf8, off, 1, flags, &nt);
     if (rc != JTK_OK) return rc;
     int32_t st = 0;
-    HIP_TRY(hipMemcpy(&st, b->status.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&st, b->status.p, 4, hipMemcpyDefault));
     if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
     if (st != JTK_OK) return fail(st, "document could not be encoded");
     if (n_tokens) *n_tokens = nt;
     if (tokens) {
         if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
-        if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDefault));
     }
     return JTK_OK;
 }
