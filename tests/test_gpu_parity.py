@@ -467,6 +467,40 @@ def test_large_batch_1gb(jt):
     b.close()
 
 
+def test_headline_corpus_at_full_size(jt):
+    """BASELINE config 3 at its full size -- the very corpus bench.py times (1M mixed UTF-8 documents, 4.1 GB, four 1 GiB
+    chunks on two scratch sets), device-resident, encode() with the special-token check.  Size-independent properties over
+    ALL documents: status 0, token offsets monotone and closed, device decode of the 1.77 G tokens reproduces the 4.1 GB byte
+    for byte with the documents' offsets; 3000 sampled documents (and the first and last of every chunk) equal the oracle."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    text, doc_off = bench.make_corpus("mixed", 1000000, 3, min(16, len(os.sched_getaffinity(0))))
+    assert len(doc_off) == 1000001 and len(text) > 4.0e9
+    dev = torch.device("cuda:0")
+    d_text, d_off = torch.from_numpy(text).to(dev), torch.from_numpy(doc_off).to(dev)
+    b = enc.new_batch()
+    nt = b.encode_device(d_text.data_ptr(), d_off.data_ptr(), len(doc_off) - 1, len(text), ordinary=False)
+    res = b.fetch()
+    assert (res.status == 0).all() and nt == len(res.tokens) and nt > 1.5e9
+    assert res.tok_off[0] == 0 and res.tok_off[-1] == nt and (np.diff(res.tok_off) >= 0).all()
+    del d_text
+    nb = b.decode_host(res.tokens, res.tok_off)
+    out, byte_off, status = b.decode_fetch()
+    assert nb == len(text) and (status == 0).all() and np.array_equal(byte_off, doc_off)
+    assert np.array_equal(out, text)
+    del out
+    rng = np.random.default_rng(2)
+    edges = [d for c in range(1, 4) for d in (np.searchsorted(doc_off, c << 30) - 1, np.searchsorted(doc_off, c << 30))]
+    for d in rng.choice(len(doc_off) - 1, 3000, replace=False).tolist() + [0, len(doc_off) - 2] + [int(e) for e in edges]:
+        doc = text[doc_off[d]:doc_off[d + 1]].tobytes()
+        assert res.doc(d).tolist() == o.encode(doc.decode("utf-8")), d
+    b.close()
+
+
 def test_many_tiny_and_empty_documents(jt):
     """200k documents of 0..5 bytes (every byte position a document start somewhere, empty documents in runs, multi-byte
     characters alone in a document): every document equals the oracle, offsets are exact; also through device decode."""
