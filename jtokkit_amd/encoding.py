@@ -442,6 +442,15 @@ class HipEncoding:
         if bs:
             np.cumsum([len(x) for x in bs], out=doc_off[1:])
         text = np.frombuffer(b"".join(bs), dtype=np.uint8) if doc_off[-1] else np.zeros(0, dtype=np.uint8)
+        if len(bs) * max(0, int(max_tokens)) > (1 << 28):
+            # a limit so large that n_docs x max_tokens ids are no sensible array: encode whole, cut on the device
+            b = self._b()
+            b.encode_host(text, doc_off, ordinary)
+            res = b.fetch()
+            if len(res.status) and res.status.min() < 0:
+                _check(int(res.status.min()))
+            kept, flag = b.truncate(max(0, int(max_tokens)))
+            return [EncodingResult(res.tokens[res.tok_off[d]:res.tok_off[d] + kept[d]].tolist(), bool(flag[d])) for d in range(len(bs))]
         toks, kept, flag, status = self._b().encode_max_tokens(text, doc_off, max_tokens, ordinary)
         if len(status) and status.min() < 0:
             _check(int(status.min()))

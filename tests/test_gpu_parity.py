@@ -335,7 +335,7 @@ def test_batch_max_tokens_fuzz(jt):
     rng = random.Random(7)
     texts = [rc.random_text(rng, rng.randint(0, 60)) for _ in range(300)]
     texts += ["", "�", "a��b", "🍕🍕🍕", "I love 🍕", "�" * 7, "é" * 9, "한국어 텍스트 " * 5]
-    for mx in (0, 1, 2, 3, 5, 8, 13, 40, 10000):
+    for mx in (0, 1, 2, 3, 5, 8, 13, 40, 10000, 2**31 - 1):
         got = enc.encode_batch_max_tokens(texts, mx, ordinary=True)
         for t, r in zip(texts, got):
             exp_toks, exp_tr = o.encode_ordinary(t, mx)
