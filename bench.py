@@ -356,13 +356,35 @@ def main():
 
     after = None
     comm = None
+    comm_error = None
     if world > 1 and not rehearsal:
-        # the library's own RCCL communicator (jtk_comm_*); the unique id travels over the process group that launched us
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        # the library's own RCCL communicator (jtk_comm_*); the unique id travels over the process group that launched us.
+        # Every rank must take the same route: a failure anywhere (no librccl for dlopen, ncclCommInitRank refused) is agreed on
+        # with an all-reduce, and the stitch then runs through torch.distributed (RCCL all the same) -- the line says which.
+        flag = torch.ones(1, device=dev)
+        uid = None
         if rank == 0:
-            idt = torch.frombuffer(bytearray(sharding.Comm.unique_id()), dtype=torch.uint8).to(dev)
-        dist.broadcast(idt, 0)
-        comm = sharding.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+            try:
+                uid = sharding.Comm.unique_id()
+            except Exception as e:                                   # noqa: BLE001 -- reported in the line
+                comm_error, flag[0] = "jtk_comm_unique_id: %s" % e, 0.0
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() > 0:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(uid), dtype=torch.uint8).to(dev)
+            dist.broadcast(idt, 0)
+            try:
+                comm = sharding.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+            except Exception as e:                                   # noqa: BLE001
+                comm_error, flag[0] = "jtk_comm_create: %s" % e, 0.0
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() == 0 and comm is not None:
+                comm.close()
+                comm = None
+        if comm is None:
+            log("jtk_comm unavailable (%s): the stitch runs through torch.distributed" % (comm_error or "another rank failed"))
+    if comm is not None:
         d_global_off = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
 
         def after(b):
@@ -372,7 +394,7 @@ def main():
             comm.stitch(off_ptr, n_docs, d_global_off.data_ptr(), b.stream())
     elif world > 1:
         def after(b):
-            # rehearsal on one GPU (gloo): same step through torch.distributed
+            # rehearsal on one GPU (gloo), or jtk_comm unavailable: the same step through torch.distributed
             _, off_ptr, _ = b.device_result()
             g_off = torch.as_tensor(_DevArray(off_ptr, n_docs + 1, "<i8"), device=dev)
             _, base = sharding.gather_shard_totals(g_off[-1:])
@@ -453,7 +475,8 @@ def main():
                                "bytes": [int(r[1]) for r in allst], "tokens": [int(r[2]) for r in allst]}
             out["rccl_world"] = comm.comm_world() if comm is not None else None
             out["stitch"] = ("jtk_comm_stitch: ncclAllGather of the shard token totals (1 x int64 per rank) on the batch's stream, every step"
-                             if comm is not None else "rehearsal on one GPU: torch.distributed (gloo) all_gather of the totals")
+                             if comm is not None else "rehearsal on one GPU: torch.distributed (gloo) all_gather of the totals" if rehearsal
+                             else "torch.distributed all_gather_into_tensor (RCCL) of the totals on the batch's stream; jtk_comm failed: %s" % comm_error)
         else:
             out["scaling_note"] = ("N = 1 times configs[2]; the N > 1 lines time configs[3] (10M English docs) sharded over N GPUs: the "
                                    "one-GPU point of that curve is the cfg4_full sub-record of this line")
