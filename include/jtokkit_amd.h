@@ -242,6 +242,9 @@ int jtk_service_submit(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_
 int jtk_service_wait(jtk_service* s, jtk_ticket* ticket, int64_t* n_tokens, int* truncated);
 int jtk_service_done(const jtk_ticket* ticket);     /* 1: the result is in (jtk_service_wait returns at once), 0: not yet -- a poll for callers that must not block */
 int jtk_service_stats(jtk_service* s, int64_t* n_batches, int64_t* n_docs);     /* device batches run, documents encoded */
+/* What one device batch takes from the queue at most (defaults: 65536 documents, 64 MiB of text; a single larger document still
+ * goes alone); the rest stays queued for the next batch.  Bounds the batch's pinned staging.  Values < 1 leave a limit as it is. */
+int jtk_service_set_limits(jtk_service* s, int64_t max_docs, int64_t max_bytes);
 
 /* ---- multi-GPU: document shards and the offset stitch ------------------------------------------------------------
  * Documents are independent (every Encoding.encode call is a pure function of one string, GptBytePairEncoding.java:71-103),

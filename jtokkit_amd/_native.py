@@ -77,6 +77,7 @@ SIGNATURES = {
     "jtk_service_wait": (C.c_int, [_p, _p, C.POINTER(_i64), C.POINTER(C.c_int)]),
     "jtk_service_done": (C.c_int, [_p]),
     "jtk_service_stats": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "jtk_service_set_limits": (C.c_int, [_p, _i64, _i64]),
     "jtk_shard_plan": (C.c_int, [_p, _i64, C.c_int, _p]),
     "jtk_comm_unique_id": (C.c_int, [_p]),
     "jtk_comm_create": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),

@@ -51,7 +51,7 @@ struct jtk_ticket {
 struct jtk_service {
     const jtk_encoding* enc = nullptr;
     int device = 0;
-    int64_t max_docs = 1 << 16, max_bytes = (int64_t)64 << 20;     // a device batch takes at most this much; the rest stays queued
+    std::atomic<int64_t> max_docs{1 << 16}, max_bytes{(int64_t)64 << 20};     // a device batch takes at most this much; the rest stays queued (jtk_service_set_limits)
     // The queue is sharded by producer thread: a producer holds its shard's lock for one push_back, so producers contend
     // with one another only when they share a shard (one mutex for all of them capped 8 producers at a fifth of what 2 reach).
     static constexpr int N_SHARDS = 16;
@@ -107,10 +107,11 @@ void worker_main(jtk_service* s) {
             // so does what exceeds max_docs / max_bytes: a device batch and its pinned staging are bounded)
             int taken = 0;
             int64_t bytes = 0;
+            const int64_t max_docs = s->max_docs.load(), max_bytes = s->max_bytes.load();
             for (auto& sh : s->shards) {
                 std::lock_guard<std::mutex> lk(sh.mu);
                 size_t k = 0;
-                while (k < sh.queue.size() && (int64_t)take.size() < s->max_docs && (take.empty() || bytes + sh.queue[k]->len <= s->max_bytes)) {
+                while (k < sh.queue.size() && (int64_t)take.size() < max_docs && (take.empty() || bytes + sh.queue[k]->len <= max_bytes)) {
                     bytes += sh.queue[k]->len;
                     take.push_back(sh.queue[k++]);
                 }
@@ -296,6 +297,13 @@ int jtk_service_encode(jtk_service* s, const uint8_t* utf8, int64_t len, uint32_
     int rc = jtk_service_submit(s, utf8, len, flags, max_tokens, tokens, tokens_cap, &t);
     if (rc != JTK_OK) return rc;
     return jtk_service_wait(s, t, n_tokens, truncated);
+}
+
+int jtk_service_set_limits(jtk_service* s, int64_t max_docs, int64_t max_bytes) {
+    if (!s) return jtk_fail_msg(JTK_ERR_INVALID_ARGUMENT, "service is NULL");
+    if (max_docs >= 1) s->max_docs.store(max_docs);
+    if (max_bytes >= 1) s->max_bytes.store(max_bytes);
+    return JTK_OK;
 }
 
 int jtk_service_stats(jtk_service* s, int64_t* n_batches, int64_t* n_docs) {

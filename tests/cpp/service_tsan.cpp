@@ -79,6 +79,7 @@ int main(int argc, char** argv) {
     for (int round = 0; round < 3; round++) {
         jtk_service* svc = nullptr;
         if (jtk_service_create(&enc, 2, &svc) != JTK_OK) return 3;
+        if (round == 1) { jtk_service_set_limits(svc, 7, 300); g_max_docs_seen.store(0); }     // tight limits: many small batches
         std::vector<std::thread> th;
         for (int t = 0; t < T; t++) {
             th.emplace_back([&, t] {
@@ -137,6 +138,7 @@ int main(int argc, char** argv) {
         }
         for (auto& x : lt) x.join();
         jtk_service_destroy(svc);
+        if (round == 1 && g_max_docs_seen.load() > 7) { fprintf(stderr, "a batch of %lld documents with max_docs = 7\n", (long long)g_max_docs_seen.load()); bad++; }
         for (auto& mine : late)
             for (auto& l : mine) {
                 if (!l.tk) continue;
