@@ -41,7 +41,9 @@ typedef enum jtk_status {
                                          jtk_encoding_create) */
     JTK_ERR_PIECE_TOO_LONG = -10,     /* a single unsplittable pre-token piece exceeds JTK_MAX_PIECE_BYTES (1 MiB;
                                          the reference spends O(n^2) on such a piece) */
-    JTK_ERR_OUT_OF_MEMORY = -11
+    JTK_ERR_OUT_OF_MEMORY = -11,
+    JTK_ERR_UNENCODABLE = -12         /* IllegalArgumentException("Unknown token for encoding: ...") TokenEncoder.java:66-68: the rank
+                                         map lacks a single-byte token and a piece of this document needs it */
 } jtk_status;
 
 /* The two split patterns of EncodingFactory.java:63 (= :77, :91) and :105. */
@@ -92,8 +94,12 @@ int jtk_device_count(void);
  * EncodingFactory.java:139-164), builds the device rank tables and uploads them to `device`.
  * `special_literals[i]` / `special_ids[i]` are the special tokens (EncodingFactory.java:24-53).
  *
- * Tables accepted: any rank map with all 256 single bytes present (the reference cannot encode arbitrary text without
- * them either) and ids < 131071; otherwise JTK_ERR_UNSUPPORTED_TABLE.  The whole-piece lookup of
+ * Tables accepted: any rank map with ids < 131071 (JTK_ERR_UNSUPPORTED_TABLE otherwise).  A map that lacks single-byte tokens
+ * is taken as the reference takes it: a document with a piece whose merge leaves such a byte alone gets JTK_ERR_UNENCODABLE
+ * (TokenEncoder.java:66-68 throws there); it needs one free id above the table's largest per missing byte.  With a token limit
+ * the status is conservative: a document is refused when such a piece lies anywhere in the bytes that were encoded (the whole
+ * document, or its leading bytes in jtk_batch_encode_max_tokens), where the reference refuses it only if the piece starts
+ * before the limit is reached.  The whole-piece lookup of
  * GptBytePairEncoding.java:81-83 is honoured for pieces of any length: for tables in which merging a token's bytes
  * reproduces the token (every table trained by byte-pair merging; the three shipped ones) it is a pure shortcut, for others
  * the unreproducible entries get a lookup of their own and the exact intra-piece cuts are switched off.

@@ -21,6 +21,7 @@ JTK_ERR_HIP = -8
 JTK_ERR_UNSUPPORTED_TABLE = -9
 JTK_ERR_PIECE_TOO_LONG = -10
 JTK_ERR_OUT_OF_MEMORY = -11
+JTK_ERR_UNENCODABLE = -12
 
 JTK_PATTERN_R50K = 0
 JTK_PATTERN_CL100K = 1

@@ -180,8 +180,8 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
     int rc = jtk_build_tables(name, pattern_kind, tiktoken, tiktoken_len, special_literals, special_ids, n_specials,
                               enc->host, err);
     if (rc != JTK_OK) { delete enc; return fail(rc, err); }
-    enc->tok_len.assign((size_t)enc->host.max_id + 1, 0);
-    for (size_t i = 0; i < enc->tok_len.size(); i++) enc->tok_len[i] = (uint32_t)enc->host.id_to_bytes[i].size();
+    enc->tok_len.assign((size_t)enc->host.max_id + 1 + (size_t)enc->host.n_missing, 1);     // (pseudo ids: one byte each)
+    for (size_t i = 0; i <= (size_t)enc->host.max_id; i++) enc->tok_len[i] = (uint32_t)enc->host.id_to_bytes[i].size();
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -260,6 +260,7 @@ int jtk_encoding_create(const char* name, int pattern_kind, const uint8_t* tikto
         for (uint32_t b = 0; b < 256; b++) if (jtk_lead_all_letters(host_uc, b)) dt.lead_letters[b >> 5] |= 1u << (b & 31);
     }
     dt.kind = pattern_kind;
+    dt.pseudo_base = enc->host.n_missing ? enc->host.pseudo_base : 0u;
     dt.n_specials = n_specials;
     {   // the literals for the device's text.contains check: offsets [n + 1] (u32), then the bytes
         std::vector<uint32_t> off((size_t)n_specials + 1, 0);
@@ -584,7 +585,8 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         w.job_tokens = d_totals + c;
         w.job_tokens_next = d_totals + c + 1;
         w.check_special = (!(flags & JTK_ENCODE_ORDINARY) && enc->dt.n_specials > 0) ? 1u : 0u;
-        w.count_only = (flags & JTK_ENCODE_COUNT_ONLY) ? 1u : 0u;
+        // (a table that lacks single bytes: the ids are needed to tell which documents cannot be encoded, also for a count)
+        w.count_only = ((flags & JTK_ENCODE_COUNT_ONLY) && !enc->dt.pseudo_base) ? 1u : 0u;
         w.inline_scan = (!fork && n_chunks == 1 && w.n_tiles >= 1 && w.n_tiles <= 1024) ? 1u : 0u;
 
         if (fork && !cs.used) { HIP_TRY(hipStreamWaitEvent(cst, b->ev_fork, 0)); cs.used = true; }
@@ -636,6 +638,7 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
         end();
         begin();
         jtk_launch_doc_offsets(w, cst);
+        if (enc->dt.pseudo_base) jtk_launch_flag_unencodable(w, enc->dt.pseudo_base, cst);
         end();
         HIP_TRY(hipGetLastError());
         if (small_to_host && !zero_copy_out) {
@@ -1144,6 +1147,7 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
         int rc = jtk_batch_encode_max_tokens(b, utf8, off2, 1, flags & JTK_ENCODE_ORDINARY, max_tokens, head.data(), &keep, &tr, &st);
         if (rc != JTK_OK) return rc;
         if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
+        if (st == JTK_ERR_UNENCODABLE) return fail(st, "Unknown token for encoding: the rank map lacks a single-byte token this text needs");
         if (st != JTK_OK) return fail(st, "document could not be encoded");
         if (truncated) *truncated = tr;
         if (n_tokens) *n_tokens = keep;
@@ -1160,6 +1164,7 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     int32_t st = 0;
     HIP_TRY(hipMemcpy(&st, b->status.p, 4, hipMemcpyDefault));
     if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
+    if (st == JTK_ERR_UNENCODABLE) return fail(st, "Unknown token for encoding: the rank map lacks a single-byte token this text needs");
     if (st != JTK_OK) return fail(st, "document could not be encoded");
     if (n_tokens) *n_tokens = nt;
     if (tokens) {

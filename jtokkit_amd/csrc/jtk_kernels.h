@@ -79,6 +79,7 @@ struct JtkDeviceTables {
     uint32_t lead_letters[8];        // bit b: every character whose UTF-8 form starts with byte b is a letter (jtk_lead_all_letters)
     JtkLongTokTable longtok;         // table entries of > 16 bytes that merging does not reproduce (n == 0 for the shipped tables)
     int kind;
+    uint32_t pseudo_base;            // ids from here on stand for single bytes that are no tokens (0: the table has all 256)
     int n_specials;
     uint32_t special_first[8];       // bit b: some special-token literal starts with byte b
     const uint8_t* special_blob;     // the literals back to back
@@ -214,5 +215,6 @@ void jtk_launch_bpe_merge(const JtkWork& w, const JtkDeviceTables& t, hipStream_
 void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s);
 void jtk_launch_pack(const JtkWork& w, hipStream_t s);
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s);
+void jtk_launch_flag_unencodable(const JtkWork& w, uint32_t pseudo_base, hipStream_t s);
 
 #endif

@@ -2019,6 +2019,29 @@ void jtk_launch_tile_scan(const JtkWork& w, hipStream_t s) {
 void jtk_launch_pack(const JtkWork& w, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)w.n_tiles), dim3(64), 0, s, w);
 }
+// Rank maps that lack single-byte tokens (rare, hand-made): a token id >= pseudo_base in the output stands for a byte the
+// table cannot encode -- the reference throws on such a piece (TokenEncoder.java:66-68).  One lane per token of the chunk:
+// the document of an offending token gets JTK_ERR_UNENCODABLE.  Runs behind k_doc_offsets (it searches tok_off).
+__global__ void __launch_bounds__(256) k_flag_unencodable(JtkWork w, uint32_t pseudo_base) {
+    const int64_t t0 = w.tile_off[0], t1 = w.tile_off[w.n_tiles];
+    const int64_t i = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t1 || (uint32_t)w.tokens[i] < pseudo_base) return;
+    // last document of the chunk whose first token is at or before i (empty documents share an offset: the last one with
+    // tokens is the one that ends after i)
+    int64_t lo = 0, hi = w.n_docs;                                  // (this chunk's documents) tok_off[lo] <= i < tok_off[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (w.tok_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    atomicMin(&w.status[lo], -12 /* JTK_ERR_UNENCODABLE */);
+    atomicMin(&w.result->worst_status, -12);
+}
+
+void jtk_launch_flag_unencodable(const JtkWork& w, uint32_t pseudo_base, hipStream_t s) {
+    if (w.n_bytes == 0) return;
+    hipLaunchKernelGGL(k_flag_unencodable, dim3((unsigned)((w.n_bytes + 255) / 256)), dim3(256), 0, s, w, pseudo_base);
+}
+
 void jtk_launch_doc_offsets(const JtkWork& w, hipStream_t s) {
     const int64_t n = w.n_docs + 1;
     hipLaunchKernelGGL(k_doc_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w);

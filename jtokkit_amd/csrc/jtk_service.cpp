@@ -282,6 +282,7 @@ int jtk_service_wait(jtk_service* s, jtk_ticket* t, int64_t* n_tokens, int* trun
     delete t;
     if (rc == JTK_ERR_UNSUPPORTED_SPECIAL) return jtk_fail_msg(rc, "Encoding special tokens is not supported yet.");
     if (rc == JTK_ERR_CAPACITY) return jtk_fail_msg(rc, "tokens buffer too small");
+    if (rc == JTK_ERR_UNENCODABLE) return jtk_fail_msg(rc, "Unknown token for encoding: the rank map lacks a single-byte token this text needs");
     if (rc != JTK_OK) return jtk_fail_msg(rc, "document could not be encoded");
     return JTK_OK;
 }

@@ -164,11 +164,25 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
     }
     t.n_tokens = (int64_t)t.bytes_to_id.size();
 
+    t.n_missing = 0;
+    t.pseudo_base = 0;
     for (int b = 0; b < 256; b++) {
         auto it = t.bytes_to_id.find(std::string(1, (char)b));
-        if (it == t.bytes_to_id.end()) { err = "rank table lacks a single-byte token; unsupported on the device path"; return JTK_ERR_UNSUPPORTED_TABLE; }
-        t.byte_rank[b] = it->second;
+        if (it != t.bytes_to_id.end()) { t.byte_rank[b] = it->second; continue; }
+        if (!t.n_missing) t.pseudo_base = t.max_id + 1;
+        t.byte_rank[b] = t.pseudo_base + (uint32_t)t.n_missing++;
     }
+    if (t.n_missing && t.pseudo_base + (uint32_t)t.n_missing - 1 > JTK_MAX_ID) {
+        err = "rank table lacks single-byte tokens and leaves no room for their pseudo ids in the device table's id range";
+        return JTK_ERR_UNSUPPORTED_TABLE;
+    }
+    // a part of a token: the token's id, or the pseudo id of a single byte that is no token
+    auto part_id = [&](const std::string& p, uint32_t& id) {
+        auto it = t.bytes_to_id.find(p);
+        if (it != t.bytes_to_id.end()) { id = it->second; return true; }
+        if (p.size() == 1 && t.n_missing) { id = t.byte_rank[(uint8_t)p[0]]; return true; }
+        return false;
+    };
 
     // pair table: every split of every token
     std::vector<std::pair<uint64_t, uint32_t>> pairs;
@@ -176,11 +190,9 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
     for (auto& kv : t.bytes_to_id) {
         const std::string& T = kv.first;
         for (size_t k = 1; k < T.size(); k++) {
-            auto a = t.bytes_to_id.find(T.substr(0, k));
-            if (a == t.bytes_to_id.end()) continue;
-            auto b = t.bytes_to_id.find(T.substr(k));
-            if (b == t.bytes_to_id.end()) continue;
-            pairs.emplace_back(jtk_pair_key(a->second, b->second), kv.second);
+            uint32_t a, b;
+            if (!part_id(T.substr(0, k), a) || !part_id(T.substr(k), b)) continue;
+            pairs.emplace_back(jtk_pair_key(a, b), kv.second);
         }
     }
     t.n_pairs = (int64_t)pairs.size();

@@ -17,7 +17,12 @@ struct JtkHostTables {
     std::vector<std::string> id_to_bytes;        // "" = id absent (p50k has a hole at 50256)
     std::vector<uint8_t> id_present;
     std::vector<std::pair<std::string, int32_t>> specials;
-    uint32_t byte_rank[256];                     // id of each single-byte token
+    uint32_t byte_rank[256];                     // id of each single-byte token; a byte that is no token gets a pseudo id
+    // Rank maps without all 256 single bytes (the reference accepts any map and fails at ENCODE time, on a piece whose merge
+    // leaves such a byte alone: TokenEncoder.java:66-68): every missing byte gets a pseudo id above the table's ids, the merge
+    // treats it as any other part, and a document whose output holds one is reported (JTK_ERR_UNENCODABLE), never emitted.
+    uint32_t pseudo_base = 0;                    // first pseudo id (0: the table has all 256 bytes)
+    int n_missing = 0;
     std::vector<JtkTok8Slot> tok8;               // whole-piece table, pieces of <= 8 bytes
     uint32_t tok8_bits = 0;
     int64_t n_tok8 = 0;

@@ -32,6 +32,8 @@ def _check(rc):
         raise UnsupportedOperationError("Encoding special tokens is not supported yet.")
     if rc == N.JTK_ERR_UNKNOWN_TOKEN:
         raise ValueError("Unknown token for decoding: " + msg)     # IllegalArgumentException
+    if rc == N.JTK_ERR_UNENCODABLE:
+        raise ValueError("Unknown token for encoding: " + msg)     # IllegalArgumentException (TokenEncoder.java:66-68)
     if rc == N.JTK_ERR_BAD_RANK_FILE:
         raise RuntimeError(msg)                                    # IllegalStateException
     raise EncodingError(rc, msg)

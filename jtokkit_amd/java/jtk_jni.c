@@ -20,6 +20,8 @@ static void throw_for(JNIEnv* env, int rc) {
             msg = "Encoding special tokens is not supported yet."; break;          /* GptBytePairEncoding.java:54 */
         case JTK_ERR_UNKNOWN_TOKEN:
         case JTK_ERR_INVALID_ARGUMENT: cls = "java/lang/IllegalArgumentException"; break;
+        case JTK_ERR_UNENCODABLE: cls = "java/lang/IllegalArgumentException";
+            msg = "Unknown token for encoding"; break;                              /* TokenEncoder.java:66-68 */
         case JTK_ERR_OUT_OF_MEMORY: cls = "java/lang/OutOfMemoryError"; break;
         default: cls = "java/lang/IllegalStateException"; break;                  /* EncodingFactory.java:142,151,162 */
     }

@@ -218,6 +218,8 @@ void* sim_tables_create(const char* name, int kind, const uint8_t* data, size_t 
 }
 void sim_tables_destroy(void* h) { delete (JtkHostTables*)h; }
 int64_t sim_tables_pairs(void* h) { return ((JtkHostTables*)h)->n_pairs; }
+// first pseudo id of a table that lacks single-byte tokens (0: none are missing)
+int64_t sim_tables_pseudo_base(void* h) { JtkHostTables* t = (JtkHostTables*)h; return t->n_missing ? (int64_t)t->pseudo_base : 0; }
 int sim_tables_bits(void* h) { return (int)((JtkHostTables*)h)->pair_bits; }
 // whole-piece table lookup (pieces of <= 8 bytes): id or -1
 int64_t sim_tok8_lookup(void* h, const uint8_t* piece, int len) {

@@ -64,9 +64,16 @@ def test_bad_rank_file_is_rejected(native):
     bad = b"IQ== 0\nnot-a-valid-line\n"
     rc_ = lib.jtk_encoding_create(b"x", 1, bad, len(bad), None, None, 0, 0, C.byref(h))
     assert rc_ == native.JTK_ERR_BAD_RANK_FILE
-    missing_bytes = b"IQ== 0\nIg== 1\n"           # parses, but lacks most single bytes
-    rc_ = lib.jtk_encoding_create(b"x", 1, missing_bytes, len(missing_bytes), None, None, 0, 0, C.byref(h))
+    # a map that lacks single bytes is accepted as the reference accepts it (the failure comes at encode time, per document:
+    # test_rank_map_without_all_single_bytes) -- unless its ids leave no room for the missing bytes' pseudo ids
+    no_room = b"IQ== 131070\n"
+    rc_ = lib.jtk_encoding_create(b"x", 1, no_room, len(no_room), None, None, 0, 0, C.byref(h))
     assert rc_ == native.JTK_ERR_UNSUPPORTED_TABLE
+    missing_bytes = b"IQ== 0\nIg== 1\n"           # parses, lacks most single bytes: table building passes, then no device here
+    rc_ = lib.jtk_encoding_create(b"x", 1, missing_bytes, len(missing_bytes), None, None, 0, 0, C.byref(h))
+    assert rc_ != native.JTK_ERR_UNSUPPORTED_TABLE and rc_ != native.JTK_ERR_BAD_RANK_FILE
+    if rc_ == native.JTK_OK:
+        lib.jtk_encoding_destroy(h)
     assert lib.jtk_encoding_create(b"x", 7, bad, len(bad), None, None, 0, 0, C.byref(h)) == native.JTK_ERR_INVALID_ARGUMENT
 
 
@@ -267,6 +274,57 @@ def test_shard_plan_matches_python_reference():
         assert b[0] == 0 and b[-1] == len(doc_off) - 1 and all(x <= y for x, y in zip(b, b[1:]))
         sizes = [int(doc_off[b[r + 1]] - doc_off[b[r]]) for r in range(world)]
         assert max(sizes) - min(sizes) <= 2 * 8192
+
+
+def test_rank_map_without_all_single_bytes(sim):
+    """A rank map need not hold all 256 single bytes (api/GptBytePairEncodingParams.java:36-46 takes any map); the reference
+    then fails on a piece whose merge leaves such a byte alone (TokenEncoder.java:66-68) and encodes every other piece.  The
+    table builder gives the missing bytes pseudo ids that take part in the merge like any id: pieces whose result holds one are
+    exactly those the oracle (built from the same map) refuses, and all other pieces merge to the oracle's tokens."""
+    import base64
+    import random
+    sim.sim_tables_pseudo_base.restype = C.c_int64
+    sim.sim_tables_pseudo_base.argtypes = [C.c_void_p]
+    rng = random.Random(3)
+    alphabet = b"abcdeqxz .\n"
+    ranks = {}
+    for ch in b"abcde .":                        # 'q', 'x', 'z' and '\n' are no tokens on their own
+        ranks[bytes([ch])] = len(ranks)
+    for tok in (b"ab", b"qa", b"abq", b"xz", b"qab", b"de", b" a", b"zq", b"qq", b"ez", b"cde", b"\n\n", b"abqa"):
+        ranks[tok] = len(ranks) + 3             # (holes in the id range)
+    data = b"\n".join(base64.b64encode(k) + b" " + str(v).encode() for k, v in sorted(ranks.items(), key=lambda kv: kv[1])) + b"\n"
+    st = C.c_int(0)
+    h = sim.sim_tables_create(b"partial", 1, data, len(data), C.byref(st))
+    assert h and st.value == 0
+    base = sim.sim_tables_pseudo_base(h)
+    assert base == max(ranks.values()) + 1
+    o = oracle_lib.OracleEncoding("partial", 1, data, {})
+    out = np.zeros(64, dtype=np.int32)
+    n_err = n_ok = 0
+    pieces = [bytes(rng.choice(alphabet) for _ in range(rng.randint(1, 12))) for _ in range(4000)] + [b"q", b"qa", b"qab", b"abqa", b"zq", b"x"]
+    for p in pieces:
+        whole = sim.sim_tok8_lookup(h, p, len(p))
+        if whole >= 0:
+            got = [whole]
+        else:
+            k = sim.sim_merge_piece(h, p, len(p), out.ctypes.data)
+            assert k > 0
+            got = out[:k].tolist()
+        if p in ranks:
+            exp = [ranks[p]]                       # GptBytePairEncoding.java:81-83
+        else:
+            try:
+                exp = o.merge_piece(p)
+            except oracle_lib.OracleError:
+                exp = None                         # TokenEncoder.java:66-68
+        if exp is None:
+            assert max(got) >= base, p
+            n_err += 1
+        else:
+            assert got == exp and max(got) < base, p
+            n_ok += 1
+    assert n_err > 100 and n_ok > 100
+    sim.sim_tables_destroy(h)
 
 
 @pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])

@@ -946,6 +946,60 @@ def test_hand_made_rank_table_with_unreproducible_entries(jt, kind):
     enc.close()
 
 
+def test_rank_map_without_all_single_bytes(jt):
+    """The reference takes any rank map (api/GptBytePairEncodingParams.java:36-46); with single bytes missing it throws on the
+    documents that need one (TokenEncoder.java:66-68: a piece whose merge leaves such a byte alone) and encodes the others.
+    A trained table with eleven single bytes removed ('q', 'z', digits 7..9, newline, two UTF-8 lead bytes ...): per document the
+    device gives JTK_ERR_UNENCODABLE exactly where the oracle built from the same map fails, and the oracle's tokens elsewhere;
+    batch, count-only, maxTokens and per-call paths."""
+    import base64
+    from jtokkit_amd import corpus
+    ranks = _train_tiny_bpe(corpus.english(40, seed=8)[0].tobytes() + "mañana 日本語 q z 789 qu iz".encode() * 20, 500)
+    for b in (b"q", b"z", b"7", b"8", b"9", b"\n", b"\xc3", b"\xe6", b"Q", b"~", b"\x00"):
+        ranks.pop(b, None)
+    enc = jt.new_custom_encoding("partial_bytes", 1, ranks, {})
+    data = b"\n".join(base64.b64encode(k) + b" " + str(v).encode() for k, v in sorted(ranks.items(), key=lambda kv: kv[1])) + b"\n"
+    o = oracle_lib.OracleEncoding("partial_bytes", 1, data, {})
+    rng = random.Random(9)
+    words = ["the", "quick", "quiz", "zebra", "a", "of", "mañana", "日本語", "789", "1", "q", "z", "~", "Queen", "size", "\n", " ", "  ", "x", "iz", "qu", "."]
+    texts = [" ".join(rng.choice(words) for _ in range(rng.randint(0, 30))) for _ in range(600)]
+    texts += [rc.random_text(rng, rng.randint(0, 80)) for _ in range(300)] + ["", "q", "the quiz", "no bad letters here", "line\nbreak"]
+    exp = []
+    for t in texts:
+        try:
+            exp.append(o.encode_ordinary(t))
+        except oracle_lib.OracleError:
+            exp.append(None)
+    assert sum(e is None for e in exp) > 100 and sum(e is not None for e in exp) > 100
+    bs = [t.encode("utf-8") for t in texts]
+    doc_off = np.zeros(len(bs) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in bs], out=doc_off[1:])
+    text = np.frombuffer(b"".join(bs), dtype=np.uint8)
+    b = enc.new_batch()
+    b.encode_host(text, doc_off, ordinary=True)
+    res = b.fetch()
+    for d, e in enumerate(exp):
+        if e is None:
+            assert res.status[d] == jt._native.JTK_ERR_UNENCODABLE, (d, texts[d])
+        else:
+            assert res.status[d] == 0 and res.doc(d).tolist() == e, (d, texts[d])
+    b.encode_host(text, doc_off, ordinary=True, count_only=True)
+    counts, status = b.fetch_counts()
+    for d, e in enumerate(exp):
+        assert (status[d] == jt._native.JTK_ERR_UNENCODABLE) == (e is None) and (e is None or counts[d] == len(e))
+    toks, kept, flag, status = b.encode_max_tokens(text, doc_off, 1000, ordinary=True)
+    for d, e in enumerate(exp):
+        assert (status[d] == jt._native.JTK_ERR_UNENCODABLE) == (e is None) and (e is None or toks[d, :kept[d]].tolist() == e)
+    b.close()
+    for t, e in list(zip(texts, exp))[:60] + list(zip(texts, exp))[-5:]:
+        if e is None:
+            with pytest.raises(ValueError, match="Unknown token for encoding"):
+                enc.encode_ordinary(t)
+        else:
+            assert enc.encode_ordinary(t) == e
+    enc.close()
+
+
 def test_many_and_long_special_tokens(jt):
     """GptBytePairEncodingParams accepts any special-token map (api/GptBytePairEncodingParams.java:36-46): 60 literals here,
     some far longer than a tile edge matters for (up to 300 bytes), with arbitrary first bytes.  encode() refuses exactly the
