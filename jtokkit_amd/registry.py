@@ -57,8 +57,9 @@ def new_custom_encoding(name, pattern_kind, mergeable_ranks, special_tokens=None
 
     mergeable_ranks: {bytes: rank}.  pattern_kind: JTK_PATTERN_R50K or JTK_PATTERN_CL100K are evaluated on the device;
     any other pattern: pass host_pattern (an object with finditer(), e.g. regex.compile(java_pattern_text)) -- the batch
-    methods then match on the host and encode the matches on the device (jtk_batch_encode_pieces).  The rank table must
-    contain all 256 single bytes (JTK_ERR_UNSUPPORTED_TABLE otherwise); entries that bytePairMerge of their own bytes does
+    methods then match on the host and encode the matches on the device (jtk_batch_encode_pieces).  A rank table need not
+    contain all 256 single bytes (text that needs a missing one raises ValueError, as TokenEncoder.java:66-68 throws); entries
+    that bytePairMerge of their own bytes does
     not reproduce are honoured through the whole-piece lookup at any length (GptBytePairEncoding.java:81-83)."""
     import base64
     lines = [base64.b64encode(k) + b" " + str(int(v)).encode() for k, v in sorted(mergeable_ranks.items(), key=lambda kv: kv[1])]
