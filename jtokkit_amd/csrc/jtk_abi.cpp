@@ -146,6 +146,53 @@ struct jtk_batch {
 #include "jtk_unicode_tables.h"
 #include "jtk_block_classify.h"
 
+// Host loops over many documents (the gather of the prefixes and the decisions of the maxTokens early exit): slices of
+// [0, n) on up to 8 threads when there is enough to share out.
+template <class F> static void host_slices(size_t n, F&& fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+    if (n < 16384 || nt == 1) { fn(0, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++) th.emplace_back([&, k] { fn((int)k, n * k / nt, n * (k + 1) / nt); });
+    for (auto& t : th) t.join();
+}
+
+// encode()'s special-token check on the host (GptBytePairEncoding.java:52-56: text.contains(literal), per document) for the entry
+// points whose text does not pass through k_pretok_split whole: one memchr pass per distinct FIRST byte of the literals (one
+// pass for the shipped encodings: every literal starts with '<'), byte ranges shared out over the host threads.
+static void find_special_docs(const jtk_encoding* enc, const uint8_t* utf8, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
+                              std::vector<uint8_t>& flag) {
+    flag.assign((size_t)(n_docs > 0 ? n_docs : 1), 0);
+    const auto& sp = enc->host.specials;
+    if (sp.empty() || n_bytes <= 0) return;
+    bool first[256] = {false};
+    for (auto& x : sp) if (!x.first.empty()) first[(uint8_t)x.first[0]] = true;
+    const size_t slice = (size_t)1 << 22;
+    const size_t n_slices = ((size_t)n_bytes + slice - 1) / slice;
+    host_slices(n_slices, [&](int, size_t lo, size_t hi) {
+        const int64_t b0 = (int64_t)(lo * slice), b1 = std::min<int64_t>(n_bytes, (int64_t)(hi * slice));   // hits that START in [b0, b1)
+        for (int fb = 0; fb < 256; fb++) {
+            if (!first[fb]) continue;
+            const uint8_t* p = utf8 + b0;
+            const uint8_t* const endp = utf8 + b1;
+            while (p < endp) {
+                p = (const uint8_t*)memchr(p, fb, (size_t)(endp - p));
+                if (!p) break;
+                const int64_t pos = p - utf8;
+                for (auto& x : sp) {
+                    const std::string& lit = x.first;
+                    if (lit.empty() || (uint8_t)lit[0] != (uint8_t)fb || pos + (int64_t)lit.size() > n_bytes) continue;
+                    if (memcmp(p, lit.data(), lit.size()) != 0) continue;
+                    const int64_t d = (std::upper_bound(doc_off, doc_off + n_docs + 1, pos) - doc_off) - 1;
+                    if (d >= 0 && d < n_docs && pos + (int64_t)lit.size() <= doc_off[d + 1]) flag[(size_t)d] = 1;   // (one value: a benign race)
+                }
+                p++;
+            }
+        }
+    });
+}
+
+
 
 extern "C" {
 
@@ -847,20 +894,9 @@ int jtk_batch_encode_pieces(jtk_batch* b, const uint8_t* utf8, const int64_t* do
     // with caller-supplied pieces that kernel does not run, so it is done here on the host
     std::vector<int64_t> special_docs;
     if (!(flags & JTK_ENCODE_ORDINARY)) {
-        for (auto& sp : b->enc->host.specials) {
-            const std::string& lit = sp.first;
-            if (lit.empty() || (int64_t)lit.size() > n_bytes) continue;
-            const uint8_t* p = utf8;
-            const uint8_t* endp = utf8 + n_bytes;
-            while (p < endp) {
-                const void* hit = memmem(p, (size_t)(endp - p), lit.data(), lit.size());
-                if (!hit) break;
-                const int64_t pos = (const uint8_t*)hit - utf8;
-                const int64_t d = (std::upper_bound(doc_off, doc_off + n_docs + 1, pos) - doc_off) - 1;
-                if (d >= 0 && d < n_docs && pos + (int64_t)lit.size() <= doc_off[d + 1]) special_docs.push_back(d);
-                p = (const uint8_t*)hit + 1;
-            }
-        }
+        std::vector<uint8_t> flag;
+        find_special_docs(b->enc, utf8, n_bytes, doc_off, n_docs, flag);
+        for (int64_t d = 0; d < n_docs; d++) if (flag[(size_t)d]) special_docs.push_back(d);
     }
     rc = run_job(b, (const uint8_t*)b->in_text.p, utf8, (const int64_t*)b->in_off.p, n_docs, n_bytes,
                  (flags | JTK_ENCODE_ORDINARY) & ~(uint32_t)JTK_ENCODE_TO_HOST, b->stream, (flags & JTK_ENCODE_TO_HOST) != 0, &pa);
@@ -1079,17 +1115,6 @@ int jtk_decode(const jtk_encoding* enc, const int32_t* ids, int64_t n, uint8_t* 
 
 }  // extern "C"
 
-// Host loops over many documents (the gather of the prefixes and the decisions of the maxTokens early exit): slices of
-// [0, n) on up to 8 threads when there is enough to share out.
-template <class F> static void host_slices(size_t n, F&& fn) {
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
-    if (n < 16384 || nt == 1) { fn(0, (size_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (unsigned k = 0; k < nt; k++) th.emplace_back([&, k] { fn((int)k, n * k / nt, n * (k + 1) / nt); });
-    for (auto& t : th) t.join();
-}
-
 // Encoding.encode(text, maxTokens) from the full token list of `text` (GptBytePairEncoding.java:90-100): the first
 // min(maxTokens, nt) tokens, backed off until decode(tokens) is a prefix of the text.  head: at least that many leading
 // tokens.  Returns the count kept; *truncated = EncodingResult.isTruncated().
@@ -1197,22 +1222,7 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
     if (n_bytes > 0 && !utf8) return fail(JTK_ERR_INVALID_ARGUMENT, "utf8 is NULL");
     const jtk_encoding* enc = b->enc;
     std::vector<uint8_t> special((size_t)(n_docs > 0 ? n_docs : 1), 0);
-    if (!(flags & JTK_ENCODE_ORDINARY)) {                            // text.contains(special) looks at the whole document (:52-56)
-        for (auto& sp : enc->host.specials) {
-            const std::string& lit = sp.first;
-            if (lit.empty() || (int64_t)lit.size() > n_bytes) continue;
-            const uint8_t* p = utf8;
-            const uint8_t* endp = utf8 + n_bytes;
-            while (p < endp) {
-                const void* hit = memmem(p, (size_t)(endp - p), lit.data(), lit.size());
-                if (!hit) break;
-                const int64_t pos = (const uint8_t*)hit - utf8;
-                const int64_t d = (std::upper_bound(doc_off, doc_off + n_docs + 1, pos) - doc_off) - 1;
-                if (d >= 0 && d < n_docs && pos + (int64_t)lit.size() <= doc_off[d + 1]) special[(size_t)d] = 1;
-                p = (const uint8_t*)hit + 1;
-            }
-        }
-    }
+    if (!(flags & JTK_ENCODE_ORDINARY)) find_special_docs(enc, utf8, n_bytes, doc_off, n_docs, special);   // text.contains(special) looks at the whole document (:52-56)
     std::vector<int64_t> active;
     active.reserve((size_t)n_docs);
     for (int64_t d = 0; d < n_docs; d++) {
