@@ -444,11 +444,11 @@ class HipEncoding:
         if bs:
             np.cumsum([len(x) for x in bs], out=doc_off[1:])
         text = np.frombuffer(b"".join(bs), dtype=np.uint8) if doc_off[-1] else np.zeros(0, dtype=np.uint8)
-        if len(bs) * max(0, int(max_tokens)) > (1 << 28):
-            # a limit so large that n_docs x max_tokens ids are no sensible array: encode whole, cut on the device
+        if self._host_pattern is not None or len(bs) * max(0, int(max_tokens)) > (1 << 28):
+            # a custom pattern (matched on the host), or a limit so large that n_docs x max_tokens ids are no sensible array:
+            # encode whole, cut on the device
+            res = self.encode_batch_packed(text, doc_off, ordinary)
             b = self._b()
-            b.encode_host(text, doc_off, ordinary)
-            res = b.fetch()
             if len(res.status) and res.status.min() < 0:
                 _check(int(res.status.min()))
             kept, flag = b.truncate(max(0, int(max_tokens)))
