@@ -501,6 +501,37 @@ def test_headline_corpus_at_full_size(jt):
     b.close()
 
 
+def test_ids_streamed_to_host_when_the_guess_is_too_small(jt):
+    """JTK_ENCODE_TO_HOST sizes the pinned ids buffer by a guess (one token per two bytes) and fills it chunk by chunk while
+    later chunks are encoded; text with more tokens than that -- emoji, digits with separators, control bytes -- makes the buffer
+    grow in mid-job, with copies of earlier chunks still in flight.  3 MB in 256 KiB host chunks: == oracle."""
+    enc = jt.get_encoding("cl100k_base")
+    o = oracle_lib.get("cl100k_base")
+    rng = random.Random(21)
+    dense = ["😀", "🤖", "🧪", "\x01", "\x7f", "1,", "²", "\u0601", "🀄", "𝔘"]
+    docs = ["".join(rng.choice(dense) for _ in range(rng.randint(1, 400))).encode("utf-8") for _ in range(6000)]
+    doc_off = np.zeros(len(docs) + 1, dtype=np.int64)
+    np.cumsum([len(d) for d in docs], out=doc_off[1:])
+    text = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    assert len(text) > 2.5e6
+    exp_tok, exp_off = o.encode_batch(text, doc_off, threads=8, ordinary=True)
+    assert len(exp_tok) * 2 > len(text)                    # more than one token per two bytes: the guess is too small
+    b = enc.new_batch()
+    b.set_option(jt._native.JTK_OPT_HOST_CHUNK_BYTES, 256 << 10)
+    for _ in range(2):
+        nt = b.encode_host(text, doc_off, ordinary=True, to_host=True)
+        res = b.host_result()
+        assert nt == len(exp_tok) and np.array_equal(res.tok_off, exp_off) and np.array_equal(res.tokens[:nt], exp_tok)
+    # and a sparse text right after on the same batch (the grown buffer is kept; no overflow this time)
+    from jtokkit_amd import corpus
+    t2, o2 = corpus.english(3000)
+    e2, eo2 = o.encode_batch(t2, o2, threads=8, ordinary=True)
+    nt = b.encode_host(t2, o2, ordinary=True, to_host=True)
+    res = b.host_result()
+    assert nt == len(e2) and np.array_equal(res.tok_off, eo2) and np.array_equal(res.tokens[:nt], e2)
+    b.close()
+
+
 def test_many_tiny_and_empty_documents(jt):
     """200k documents of 0..5 bytes (every byte position a document start somewhere, empty documents in runs, multi-byte
     characters alone in a document): every document equals the oracle, offsets are exact; also through device decode."""
