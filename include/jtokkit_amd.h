@@ -70,7 +70,8 @@ enum {
     JTK_OPT_CHUNK_BYTES = 1,      /* target bytes of text per chunk, device-resident input (default 1 GiB: large chunks
                                      have fewer launches and kernel tails; env JTK_CHUNK_BYTES).  Scratch: ~30 bytes per
                                      byte of chunk per set */
-    JTK_OPT_CHUNKS_IN_FLIGHT = 2, /* scratch sets / streams, 1..4 (default 2; env JTK_CHUNKS_IN_FLIGHT) */
+    JTK_OPT_CHUNKS_IN_FLIGHT = 2, /* scratch sets / streams, 1..4 (default 2, and 3 for host input with JTK_ENCODE_TO_HOST unless chosen
+                                     here or by env JTK_CHUNKS_IN_FLIGHT: the host waits once per chunk there, two sets stall) */
     JTK_OPT_HOST_CHUNK_BYTES = 3, /* ... host input (default 32 MiB: the copy of one chunk overlaps the kernels of another;
                                      env JTK_HOST_CHUNK_BYTES) */
     JTK_OPT_REUSE_CHUNK_PLAN = 4  /* 1: jtk_batch_encode_device keeps the chunk plan of the last batch while it is handed the same

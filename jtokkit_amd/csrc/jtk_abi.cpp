@@ -93,6 +93,7 @@ struct jtk_batch {
     size_t h_info_cap = 0;
     ChunkSet set[MAX_SETS];
     int n_sets = 2;                      // chunks in flight (JTK_OPT_CHUNKS_IN_FLIGHT)
+    bool n_sets_chosen = false;          // by the caller or the environment (else a job that streams ids to the host takes 3)
     int64_t chunk_bytes = (int64_t)1 << 30;    // JTK_OPT_CHUNK_BYTES: device-resident input (large chunks: fewer launches and kernel tails)
     int64_t host_chunk_bytes = (int64_t)32 << 20;   // JTK_OPT_HOST_CHUNK_BYTES: host input (small chunks: copies overlap kernels)
     // the whole batch
@@ -353,7 +354,7 @@ int jtk_batch_create(const jtk_encoding* enc, jtk_batch** out) {
     b->enc = enc;
     if (const char* e = getenv("JTK_CHUNK_BYTES")) { const long long v = atoll(e); if (v >= (1 << 20)) b->chunk_bytes = v; }
     if (const char* e = getenv("JTK_HOST_CHUNK_BYTES")) { const long long v = atoll(e); if (v >= (1 << 16)) b->host_chunk_bytes = v; }
-    if (const char* e = getenv("JTK_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= MAX_SETS) b->n_sets = v; }
+    if (const char* e = getenv("JTK_CHUNKS_IN_FLIGHT")) { const int v = atoi(e); if (v >= 1 && v <= MAX_SETS) { b->n_sets = v; b->n_sets_chosen = true; } }
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->host_result_own, sizeof(JtkResult), hipHostMallocDefault);
     b->host_result = b->host_result_own;
@@ -413,6 +414,7 @@ int jtk_batch_set_option(jtk_batch* b, int option, int64_t value) {
         case JTK_OPT_CHUNKS_IN_FLIGHT:
             if (value < 1 || value > MAX_SETS) return fail(JTK_ERR_INVALID_ARGUMENT, "chunks in flight: 1..4");
             b->n_sets = (int)value;
+            b->n_sets_chosen = true;
             return JTK_OK;
         case JTK_OPT_REUSE_CHUNK_PLAN:
             b->reuse_plan = value != 0;
@@ -531,7 +533,11 @@ int run_job(jtk_batch* b, const uint8_t* d_text, const uint8_t* h_text, const in
             uint32_t flags, hipStream_t s, bool to_host, const PieceArgs* pieces = nullptr) {
     const jtk_encoding* enc = b->enc;
     const int n_chunks = (int)b->chunk_doc.size() - 1;
-    const int n_sets = n_chunks < b->n_sets ? (n_chunks < 1 ? 1 : n_chunks) : b->n_sets;
+    // (ids streamed to the host chunk by chunk: the host waits for a chunk's scan before it can issue that chunk's copy, one
+    // chunk behind the enqueueing -- with two sets that wait stalls the pipeline: 404 ms per step on the headline corpus against
+    // 163 with three, profiles/r03_experiments/r03bc_e2e_memcpy.txt -- so such a job takes three unless the caller chose)
+    const int want_sets = (!b->n_sets_chosen && to_host && h_text && b->n_sets < 3) ? 3 : b->n_sets;   // (host input: small chunks, small sets)
+    const int n_sets = n_chunks < want_sets ? (n_chunks < 1 ? 1 : n_chunks) : want_sets;
     int rc;
     // batch-wide buffers
     const size_t status_bytes = align_up((size_t)(n_docs > 0 ? n_docs : 1) * 4, 16);
