@@ -1190,17 +1190,17 @@ int jtk_encode(jtk_batch* b, const uint8_t* utf8, int64_t len, uint32_t flags, i
     }
     const int64_t off[2] = {0, len};
     int64_t nt = 0;
-    int rc = jtk_batch_encode(b, utf8, off, 1, flags, &nt);
+    // (the result comes back with the job -- status and ids in pinned host memory -- instead of two more copies behind it)
+    int rc = jtk_batch_encode(b, utf8, off, 1, (flags & ~(uint32_t)JTK_ENCODE_COUNT_ONLY) | JTK_ENCODE_TO_HOST, &nt);
     if (rc != JTK_OK) return rc;
-    int32_t st = 0;
-    HIP_TRY(hipMemcpy(&st, b->status.p, 4, hipMemcpyDefault));
+    const int32_t st = b->r_status[0];
     if (st == JTK_ERR_UNSUPPORTED_SPECIAL) return fail(st, "Encoding special tokens is not supported yet.");
     if (st == JTK_ERR_UNENCODABLE) return fail(st, "Unknown token for encoding: the rank map lacks a single-byte token this text needs");
     if (st != JTK_OK) return fail(st, "document could not be encoded");
     if (n_tokens) *n_tokens = nt;
     if (tokens) {
         if (tokens_cap < nt) return fail(JTK_ERR_CAPACITY, "tokens buffer too small");
-        if (nt > 0) HIP_TRY(hipMemcpy(tokens, b->tokens.p, (size_t)nt * 4, hipMemcpyDefault));
+        if (nt > 0) memcpy(tokens, b->r_tokens, (size_t)nt * 4);
     }
     return JTK_OK;
 }
