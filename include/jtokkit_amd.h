@@ -173,7 +173,8 @@ int jtk_batch_result(jtk_batch* b, int64_t* n_tokens, int64_t* n_docs, int32_t* 
  * tok_off[n_docs + 1], status[n_docs]; any of them may be NULL. */
 int jtk_batch_fetch(jtk_batch* b, int32_t* tokens, int64_t tokens_cap, int64_t* tok_off, int32_t* status);
 
-/* Device pointers of the last result (valid until the next encode on this batch). */
+/* Device pointers of the last result (valid until the next encode on this batch).  After a host-input job of <= 128 KiB with
+ * JTK_ENCODE_TO_HOST they are addresses of pinned host memory the device can reach (the kernels wrote the result there). */
 int jtk_batch_device_result(jtk_batch* b, const int32_t** d_tokens, const int64_t** d_tok_off,
                             const int32_t** d_status);
 
