@@ -1346,7 +1346,9 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
                     }
                     if (k < 0) { again[slice].push_back(d); continue; }
                     int tr = 0;
-                    const int64_t keep = jtk_max_tokens_backoff(enc, utf8 + doc_off[d], len, toks + t0, k, max_tokens, &tr);
+                    // (the back-off looks at the text around the cut only: that is inside the prefix, which is in the cache -- the
+                    // document itself is a cold line per look)
+                    const int64_t keep = jtk_max_tokens_backoff(enc, gtext.data() + goff[i], len, toks + t0, k, max_tokens, &tr);
                     if (keep > 0) memcpy(tokens + d * max_tokens, toks + t0, (size_t)keep * 4);
                     kept[d] = keep;
                     if (truncated) truncated[d] = (uint8_t)tr;
