@@ -121,6 +121,7 @@ struct jtk_batch {
     int32_t* h_status = nullptr; size_t h_status_cap = 0;
     uint8_t* h_small = nullptr; size_t h_small_cap = 0;   // a small job's whole `out` block (pinned)
     uint8_t* h_in = nullptr; size_t h_in_cap = 0;         // a tiny host job's offsets and text, side by side (pinned)
+    uint8_t* h_gather = nullptr; size_t h_gather_cap = 0; // jtk_batch_encode_max_tokens: the documents' leading bytes, gathered (pinned)
     // where the host copy of the last job's result is: the buffers above, or inside h_small
     const int32_t* r_tokens = nullptr; const int64_t* r_tok_off = nullptr; int32_t* r_status = nullptr;
     bool have_host_result = false;
@@ -392,6 +393,7 @@ void jtk_batch_destroy(jtk_batch* b) {
     if (b->host_result_own) (void)hipHostFree(b->host_result_own);
     if (b->h_small) (void)hipHostFree(b->h_small);
     if (b->h_in) (void)hipHostFree(b->h_in);
+    if (b->h_gather) (void)hipHostFree(b->h_gather);
     if (b->host_plan) (void)hipHostFree(b->host_plan);
     if (b->h_tokens) (void)hipHostFree(b->h_tokens);
     if (b->h_tok_off) (void)hipHostFree(b->h_tok_off);
@@ -1248,7 +1250,7 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
     const int64_t margin = 16;
     const int64_t cb = b->host_chunk_bytes < b->chunk_bytes ? b->host_chunk_bytes : b->chunk_bytes;   // a group stays one chunk
     int64_t P = max_tokens > ((int64_t)1 << 40) ? (int64_t)1 << 44 : 8 * max_tokens + 64;
-    std::vector<uint8_t> gtext;
+    uint8_t* gtext = nullptr;                                        // (pinned: the prefixes go down by DMA while the kernels start)
     std::vector<int64_t> goff, next_active;
     std::vector<uint64_t> mask;
     const bool trace = getenv("JTK_MAXTOK_TRACE") != nullptr;
@@ -1272,17 +1274,18 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
                 a1++;
             }
             double t0 = now();
-            gtext.resize((size_t)gbytes + 1);
+            { const int prc = ensure_pinned((void**)&b->h_gather, &b->h_gather_cap, (size_t)gbytes + 64, 0); if (prc) return prc; }
+            gtext = b->h_gather;
             host_slices(a1 - a0, [&](int, size_t lo, size_t hi) {
                 for (size_t i = lo; i < hi; i++)
-                    memcpy(gtext.data() + goff[i], utf8 + doc_off[active[a0 + i]], (size_t)(goff[i + 1] - goff[i]));
+                    memcpy(gtext + goff[i], utf8 + doc_off[active[a0 + i]], (size_t)(goff[i + 1] - goff[i]));
             });
             const int64_t ng = (int64_t)(a1 - a0);
             int64_t nt = 0;
             const int64_t save_host_chunk = b->host_chunk_bytes;
             if (gbytes > cb) b->host_chunk_bytes = gbytes;           // a single document above the host chunk size: still one chunk
             double t1 = now(); t_gather += t1 - t0;
-            int rc = jtk_batch_encode(b, gtext.data(), goff.data(), ng, JTK_ENCODE_ORDINARY | JTK_ENCODE_TO_HOST, &nt);
+            int rc = jtk_batch_encode(b, gtext, goff.data(), ng, JTK_ENCODE_ORDINARY | JTK_ENCODE_TO_HOST, &nt);
             b->host_chunk_bytes = save_host_chunk;
             double t2 = now(); t_enc += t2 - t1;
             if (rc != JTK_OK) return rc;
@@ -1319,7 +1322,7 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
                     if (p == len) k = n;
                     else {
                         // the last safe piece start at or before p - margin
-                        const uint8_t* t = gtext.data() + goff[i];
+                        const uint8_t* t = gtext + goff[i];
                         int64_t q = 0;
                         for (int64_t pos = goff[i] + p - margin; pos > goff[i]; ) {
                             uint64_t w = mask[(size_t)(pos >> 6)];
@@ -1348,7 +1351,7 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
                     int tr = 0;
                     // (the back-off looks at the text around the cut only: that is inside the prefix, which is in the cache -- the
                     // document itself is a cold line per look)
-                    const int64_t keep = jtk_max_tokens_backoff(enc, gtext.data() + goff[i], len, toks + t0, k, max_tokens, &tr);
+                    const int64_t keep = jtk_max_tokens_backoff(enc, gtext + goff[i], len, toks + t0, k, max_tokens, &tr);
                     if (keep > 0) memcpy(tokens + d * max_tokens, toks + t0, (size_t)keep * 4);
                     kept[d] = keep;
                     if (truncated) truncated[d] = (uint8_t)tr;
