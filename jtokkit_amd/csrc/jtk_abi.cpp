@@ -1255,6 +1255,7 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
     std::vector<uint64_t> mask;
     const bool trace = getenv("JTK_MAXTOK_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     double t_gather = 0, t_enc = 0, t_dec = 0, t_mask = 0;
     while (!active.empty()) {
         next_active.clear();
@@ -1361,8 +1362,8 @@ int jtk_batch_encode_max_tokens(jtk_batch* b, const uint8_t* utf8, const int64_t
             t_dec += now() - t2;
             a0 = a1;
         }
-        if (trace) fprintf(stderr, "[max_tokens] P=%lld docs=%zu -> %zu again; gather %.2f encode %.2f mask %.2f decide(incl. mask) %.2f ms\n",
-                           (long long)P, active.size(), next_active.size(), t_gather, t_enc, t_mask, t_dec);
+        if (trace) fprintf(stderr, "[max_tokens] P=%lld docs=%zu -> %zu again; gather %.2f encode %.2f mask %.2f decide(incl. mask) %.2f ms; %.2f ms since the rounds began\n",
+                           (long long)P, active.size(), next_active.size(), t_gather, t_enc, t_mask, t_dec, now() - t_begin);
         active.swap(next_active);
         P = P > ((int64_t)1 << 40) ? P : P * 4;
     }
