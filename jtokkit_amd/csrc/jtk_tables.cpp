@@ -15,6 +15,18 @@
 #include "../../include/jtokkit_amd.h"
 #include "jtk_merge_core.h"
 
+// Slot load of the hash tables.  A probe that misses in a slot which turned a key away costs a second, dependent fetch, and
+// what a lookup costs on the device is fetches, not bytes: HBM has 288 GB and the tables do not fit the 4 MB L2 of an XCD at any
+// sensible load anyway (the Infinity Cache serves them), so they are built SPARSE -- measured on a 1 GiB chunk of mixed text
+// (r03, profiles/r03_experiments/r03b[ijk]_table_loads.txt): loads 0.4 / 0.5 (whole-piece / pair table; 8.5 MB in all): resolve
+// 2.53 ms, merge 2.43; 0.2 / 0.2: 2.41 / 2.18; 0.12 / 0.10 (35 MB): 2.42 / 2.06; sparser than that changes nothing.
+#ifndef JTK_TOK_TABLE_LOAD
+#define JTK_TOK_TABLE_LOAD 0.12
+#endif
+#ifndef JTK_PAIR_TABLE_LOAD
+#define JTK_PAIR_TABLE_LOAD 0.10
+#endif
+
 namespace {
 
 int b64val(int c) {
@@ -198,9 +210,9 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
     t.n_pairs = (int64_t)pairs.size();
     std::sort(pairs.begin(), pairs.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
         return x.second != y.second ? x.second < y.second : x.first < y.first; });      // by rank: frequent merges first
-    // two-choice cuckoo, two slots per bucket, primary first.  Slot load 0.5: one bucket in twelve turns a key away.
+    // two-choice cuckoo, two slots per bucket, primary first; sparse (JTK_PAIR_TABLE_LOAD above): hardly any bucket turns a key away
     {
-        double load = 0.5;
+        double load = JTK_PAIR_TABLE_LOAD;
         for (;; load *= 0.9) {
             const uint32_t nb = (uint32_t)((double)pairs.size() / (2.0 * load)) + 16;
             std::vector<uint32_t> h1(pairs.size()), h2(pairs.size()), where;
@@ -266,7 +278,7 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
     }
     {
-        double load = 0.4;
+        double load = JTK_TOK_TABLE_LOAD;
         for (;; load *= 0.9) {
             const uint32_t ns = (uint32_t)((double)shorts.size() / load) + 16;
             std::vector<uint32_t> h1(shorts.size()), h2(shorts.size()), where;
@@ -299,7 +311,7 @@ int jtk_build_tables(const char* name, int kind, const uint8_t* data, size_t len
         }
         t.n_tok16 = (int64_t)mids.size();
         std::sort(mids.begin(), mids.end(), [](const JtkTok16Slot& x, const JtkTok16Slot& y) { return x.id < y.id; });
-        double load = 0.4;
+        double load = JTK_TOK_TABLE_LOAD;
         for (;; load *= 0.9) {
             const uint32_t ns = (uint32_t)((double)mids.size() / load) + 16;
             std::vector<uint32_t> h1(mids.size()), h2(mids.size()), where;
